@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the PPCA EM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one full EM iteration over the synthetic dataset (fused E-step + M-step
+statistics pass, one RCCL all-reduce of the packed statistics when N > 1, on-device
+finalisation into the next model), inputs resident in HBM.  Workload = BASELINE.json's
+metric configuration: N = 10M samples x d = 256 x state_size = 10, 30 % iid masking,
+sharded by contiguous row blocks over the ranks (total work fixed => strong scaling).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # fp64 vector = fp64 matrix spec
+
+
+def algorithmic_bytes_per_sample(d: int) -> float:
+    return 8.0 * d + d / 8.0 + 8.0  # X row (f64) + bitmask + weight
+
+
+def algorithmic_flops_per_sample(d: int, k: int, m: float) -> float:
+    kp = k * (k + 1) / 2
+    return 4 * m * kp + 4 * m * k + 2 * d * k + 2 * k ** 3
+
+
+def cpu_baseline(ds, start_model, n_total: int, d: int, k: int, rows: int):
+    """Times the oracle (literal restatement of the reference's rayon path, OpenMP) on a
+    bounded sample of the same workload, on this box's host cores."""
+    from oracle import ppca_oracle as o
+
+    x = ds._slice(0, rows).numpy()
+    c, mu, s = start_model.transform, start_model.mean, start_model.isotropic_noise
+    o.iterate(x[:256], s, c, mu)  # warm up (thread pool, page faults)
+    times = []
+    t_end = time.time() + 25.0
+    while len(times) < 3 and (not times or time.time() < t_end):
+        t0 = time.perf_counter()
+        o.iterate(x, s, c, mu)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    return {
+        "value": 1.0 / (t * n_total / rows),
+        "unit": "EM iters/sec",
+        "cores": o.num_threads(),
+        "kind": "port",
+        "sample": f"{rows} of {n_total} rows of the same dataset, {len(times)} timed iterate() calls "
+                  f"(median {t:.3f} s), scaled linearly in N",
+        "samples_per_sec": rows / t,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--mask", type=float, default=0.3)
+    ap.add_argument("--cpu-rows", type=int, default=20_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import ppca_rs_amd as P
+    from ppca_rs_amd import _lib
+    from ppca_rs_amd.distributed import ShardedEM, shard_bounds
+
+    ctx = _lib.Context(local_rank)
+    _lib.set_default_context(ctx)
+
+    n, d, k = args.n, args.d, args.k
+    # SURVEY.md 8(d) seeds: C_true 1011, mean_true 1012, data 1013; start model 2011
+    c_true = np.random.default_rng(1011).standard_normal((d, k))
+    mean_true = np.random.default_rng(1012).standard_normal(d)
+    truth = P.PPCAModel(0.1, c_true, mean_true)
+    a, b = shard_bounds(n, world, rank)
+    spec = _lib.SynthSpec(a, b - a, d, k, 0.1, args.mask, 0, 0, 1013,
+                          truth._c.ctypes.data_as(_lib.c_double_p), truth._mean.ctypes.data_as(_lib.c_double_p))
+    import ctypes as C
+
+    h = C.c_void_p()
+    _lib.check(_lib.lib().ppca_dataset_generate(ctx.handle, C.byref(spec), C.byref(h)))
+    shard = P.Dataset._wrap(h, ctx)
+    c0 = np.random.default_rng(2011).standard_normal(d * k).reshape((k, d)).T.copy()
+    start = P.PPCAModel(1.0, c0, np.zeros(d))  # as PPCAModel::init (ppca_model.rs:51-70)
+
+    em = ShardedEM(shard, start)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        em.step()
+    sync()
+    ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        em.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = ctx.kernel_time(reset=True)
+    ctx.enable_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    llk_last = em.llk_of_previous()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        iters_per_s = args.steps / elapsed
+        rows_local = b - a
+        kern_avg_ms = kern_ms / max(launches, 1)
+        bytes_launch = rows_local * algorithmic_bytes_per_sample(d)
+        flops_launch = rows_local * algorithmic_flops_per_sample(d, k, d * (1.0 - args.mask))
+        achieved = bytes_launch / (kern_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "EM iters/sec (and samples/sec/iter) at N=10M d=256 k=10, 30% masked",
+            "value": iters_per_s,
+            "unit": "EM iters/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"PPCA EM, N={n} samples x d={d}, state_size={k}, {int(100 * args.mask)}% iid masked, "
+                                   f"{world} contiguous row shard(s), one all-reduce of {_lib.lib().ppca_stats_len(d, k)} f64 per step",
+                       "n_samples": n, "d": d, "state_size": k, "mask_prob": args.mask, "parallelism": f"dp{world}"},
+            "samples_per_sec": n * iters_per_s,
+            "llk_per_sample_last_input_model": llk_last / n,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "ppca::pass_kernel<10, true>",
+                "kernel_avg_ms": kern_avg_ms,
+                "kernel_launches": launches,
+                "algorithmic_bytes_per_launch": bytes_launch,
+                "fp64_achieved_tflops": flops_launch / (kern_avg_ms * 1e-3) / 1e12,
+                "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+                "fp64_frac": flops_launch / (kern_avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(shard, start, n, d, k, min(args.cpu_rows, rows_local))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,221 @@
+/*
+ * ppca_hip.h -- C-ABI of the MI355X-native PPCA EM engine (libppca_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of viodotcom/ppca_rs: the EM hot path
+ * (per-sample masked posterior inference + M-step sufficient statistics) and the
+ * passes that share its per-sample math (llk / llks / infer / smooth /
+ * extrapolate).  The reference has no FFI seam of its own: its only boundary is
+ * the PyO3 class surface (src/python_bindings.rs:15-26).  Each entry point below
+ * names the reference item it replaces (paths relative to the reference root);
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; opaque handles own device memory
+ *   - every function returns 0 (PPCA_OK) or a negative ppca_status; the message of
+ *     the last failure on the calling thread is ppca_last_error()
+ *   - "host" pointers are caller-owned host memory; "dev" pointers are device
+ *     memory on the context's GPU (e.g. a torch tensor's data_ptr())
+ *   - matrices are row-major float64; transform C is (d x k), mean is (d)
+ *   - a dataset entry is OBSERVED iff it is finite (dataset.rs:19-22); masked
+ *     entries keep their non-finite value in device memory and are removed by
+ *     selection, never by multiplication (utils.rs:118-127)
+ *   - all work is enqueued on the context's stream; entry points that return
+ *     host values synchronise that stream, the *_async/_dev ones do not
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     fails with PPCA_ERR_HIP
+ */
+#ifndef PPCA_HIP_H
+#define PPCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPCA_ABI_VERSION 1
+
+typedef enum ppca_status {
+    PPCA_OK = 0,
+    PPCA_ERR_INVALID = -1,     /* bad argument / shape mismatch (reference: panics, output_covariance.rs:124) */
+    PPCA_ERR_HIP = -2,         /* HIP runtime failure or no device */
+    PPCA_ERR_UNSUPPORTED = -3, /* (d, k) outside what the kernels cover */
+    PPCA_ERR_EMPTY = -4,       /* empty dataset (reference: assert, ppca_model.rs:52; expect :358) */
+    PPCA_ERR_NUMERIC = -5      /* e.g. singular mean-prior covariance (prior.rs:40) */
+} ppca_status;
+
+typedef struct ppca_ctx ppca_ctx;         /* one GPU + one stream */
+typedef struct ppca_dataset ppca_dataset; /* device-resident Dataset (dataset.rs:93-100) */
+typedef struct ppca_model ppca_model;     /* device-resident PPCAModel (ppca_model.rs:18-22,40) */
+
+/* Prior (prior.rs:8-15).  Host pointers; mean is (d), mean_covariance is (d x d). */
+typedef struct ppca_prior {
+    int32_t has_mean_prior;            /* with_mean_prior            prior.rs:32-45 */
+    const double *mean;
+    const double *mean_covariance;
+    int32_t has_isotropic_noise_prior; /* with_isotropic_noise_prior prior.rs:49-56 */
+    double isotropic_noise_alpha;
+    double isotropic_noise_beta;
+    double transformation_precision;   /* with_transformation_precision prior.rs:60-65 */
+} ppca_prior;
+
+/* Synthetic data = the model's own generative process (sample_one,
+ * ppca_model.rs:164-181): y = C n1 + mean + sigma n2, entry dropped with
+ * probability mask_prob (mask_kind 0) or one cyclic run of mask_run dims per
+ * sample (mask_kind 1).  Counter-based RNG keyed by (seed, GLOBAL row, column):
+ * a shard [row_offset, row_offset + n_rows) of the same seed holds the same rows
+ * whatever the number of shards. */
+typedef struct ppca_synth_spec {
+    int64_t row_offset;
+    int64_t n_rows;
+    int32_t d;
+    int32_t k;
+    double sigma;
+    double mask_prob;
+    int32_t mask_kind;
+    int32_t mask_run;
+    uint64_t seed;
+    const double *transform; /* host (d x k) ground-truth C */
+    const double *mean;      /* host (d) */
+} ppca_synth_spec;
+
+/* ------------------------------------------------------------------ misc */
+const char *ppca_last_error(void);
+int32_t ppca_abi_version(void);
+/* 1 when (d, k) runs on the fused single-pass kernel, 0 when it runs on the
+ * generic split pipeline, negative if unsupported. */
+int32_t ppca_path_kind(int32_t d, int32_t k);
+
+/* --------------------------------------------------------------- context */
+/* device_id < 0: use the current HIP device.  stream: a hipStream_t to enqueue
+ * on (NULL = the library creates its own).  Replaces rayon's process-global pool
+ * (rayon parallel iterators, ppca_model.rs:221-227 et al.). */
+int ppca_ctx_create(int32_t device_id, void *stream, ppca_ctx **out);
+int ppca_ctx_destroy(ppca_ctx *ctx);
+int ppca_ctx_set_stream(ppca_ctx *ctx, void *stream);
+int ppca_ctx_synchronize(ppca_ctx *ctx);
+/* When enabled, the library brackets every launch of the dominant EM kernel with
+ * HIP events on the context stream; ppca_ctx_kernel_time returns the summed
+ * duration and launch count since the last reset (synchronises). */
+int ppca_ctx_enable_timing(ppca_ctx *ctx, int32_t enabled);
+int ppca_ctx_kernel_time(ppca_ctx *ctx, double *total_ms, int64_t *launches, int32_t reset);
+
+/* --------------------------------------------------------------- dataset */
+/* Dataset(ndarray, weights=None)  src/python_bindings.rs:34-64.
+ * x: (n x d) float64 with element strides (row_stride, col_stride) in ELEMENTS
+ * (numpy views of any layout, :45); weights: n or NULL (= 1.0, dataset.rs:153-158). */
+int ppca_dataset_from_host(ppca_ctx *ctx, const double *x, int64_t n, int32_t d, int64_t row_stride,
+                           int64_t col_stride, const double *weights, ppca_dataset **out);
+/* Borrow device memory (row-major n x d, weights n or NULL); not freed by the library. */
+int ppca_dataset_from_device(ppca_ctx *ctx, const double *x_dev, int64_t n, int32_t d, const double *weights_dev,
+                             ppca_dataset **out);
+/* PPCAModel::sample (ppca_model.rs:186-191) with a seed, generated on device. */
+int ppca_dataset_generate(ppca_ctx *ctx, const ppca_synth_spec *spec, ppca_dataset **out);
+/* Dataset::with_weights dataset.rs:171-176: shares the rows, new weights (host or device). */
+int ppca_dataset_with_weights(ppca_dataset *ds, const double *weights_host, const double *weights_dev,
+                              ppca_dataset **out);
+/* DatasetChunks src/python_bindings.rs:151-165: rows [start, start+len), shares storage. */
+int ppca_dataset_slice(ppca_dataset *ds, int64_t start, int64_t len, ppca_dataset **out);
+/* Dataset.concat src/python_bindings.rs:121-133 */
+int ppca_dataset_concat(ppca_ctx *ctx, ppca_dataset *const *parts, int32_t n_parts, ppca_dataset **out);
+int ppca_dataset_free(ppca_dataset *ds);
+int64_t ppca_dataset_len(const ppca_dataset *ds);        /* __len__ :94-96 */
+int32_t ppca_dataset_output_size(const ppca_dataset *ds); /* output_size :98-100 */
+const double *ppca_dataset_device_x(const ppca_dataset *ds);
+const double *ppca_dataset_device_weights(const ppca_dataset *ds);
+/* Dataset.numpy :81-92 / masked_vector dataset.rs:64-72: masked entries come back NaN. */
+int ppca_dataset_to_host(ppca_dataset *ds, double *out);
+int ppca_dataset_weights_to_host(ppca_dataset *ds, double *out); /* weights :106-108 */
+/* Dataset::empty_dimensions dataset.rs:194-222: flags[j] = 1 iff dim j is masked in every sample. */
+int ppca_dataset_empty_dimensions(ppca_dataset *ds, int32_t *flags);
+
+/* ----------------------------------------------------------------- model */
+/* PPCAModel::new ppca_model.rs:43-48 (isotropic_noise = sigma, transform d x k, mean d). */
+int ppca_model_create(ppca_ctx *ctx, int32_t d, int32_t k, double sigma, const double *transform,
+                      const double *mean, ppca_model **out);
+/* An uninitialised model buffer of the given shape (target of ppca_em_finalize). */
+int ppca_model_alloc(ppca_ctx *ctx, int32_t d, int32_t k, ppca_model **out);
+int ppca_model_download(ppca_model *m, double *sigma, double *transform, double *mean);
+int ppca_model_free(ppca_model *m);
+int32_t ppca_model_output_size(const ppca_model *m);
+int32_t ppca_model_state_size(const ppca_model *m);
+
+/* ------------------------------------------------- EM step (the hot path) */
+/* Packed sufficient statistics of one shard (all linear in the sample weights,
+ * hence additive across GPUs -- the ONE collective of the path is a sum of this
+ * buffer).  k' = k(k+1)/2, symmetric entries lower-packed (e = a(a+1)/2 + b, b <= a):
+ *   cross [d*k]   sum_i w_i x~_ij z_i              ppca_model.rs:281-293
+ *   S     [d*k']  sum_i w_i m_ij (z_i z_i^T + Sigma_i)   :297-306
+ *   U     [d*k]   sum_i w_i m_ij z_i               (for total_deviation, :338-347)
+ *   sumx  [d]     sum_i w_i x~_ij
+ *   totals[d]     sum_i w_i m_ij                   :348
+ *   scalars[8]    square_error (:345), deviations_square_sum (:346),
+ *                 llk of the INPUT model (:142-149), sum_i w_i, #non-empty samples, 0, 0, 0
+ * with x~ = x - mean on observed dims (0 elsewhere), z_i/Sigma_i the posterior of
+ * the INPUT model (infer_one :195-208). */
+int64_t ppca_stats_len(int32_t d, int32_t k);
+
+/* E-step + all M-step reductions over the dataset's rows in ONE streaming pass
+ * (replaces infer :221-227 + the four sweeps of iterate_with_prior :278-358).
+ * stats_dev: device buffer of ppca_stats_len doubles, overwritten.  Asynchronous. */
+int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_dev);
+/* M-step finalisation on device from (all-reduced) statistics: d row solves
+ * (:309-322, keep the old row when the system is singular), sigma^2 (:360-371),
+ * mean (:373-377); prior hooks :307-308, :367-368, :379-384.  Asynchronous
+ * unless a mean prior is given.  out may not alias model_in. */
+int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const double *stats_dev, const ppca_prior *prior,
+                     ppca_model *out);
+/* Same arithmetic on host buffers (no GPU needed): used after a CPU-side
+ * reduction and by the mean-prior branch. */
+int ppca_em_finalize_host(int32_t d, int32_t k, double sigma, const double *transform, const double *mean,
+                          const double *stats, const ppca_prior *prior, double *sigma_out, double *transform_out,
+                          double *mean_out);
+/* PPCAModel::iterate / iterate_with_prior (ppca_model.rs:267-269, :277-393;
+ * src/python_bindings.rs:496-507) on a single GPU = accumulate + finalize.
+ * llk_in (nullable): log-likelihood of model_in, a by-product of the pass
+ * (saves the trainer's extra llk sweep, python/ppca_rs/__init__.py:51).
+ * Reading llk_in synchronises; with llk_in == NULL the call is asynchronous. */
+int ppca_em_step(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model_in, const ppca_prior *prior,
+                 ppca_model *out, double *llk_in);
+/* Debug/parity: the packed statistics copied to host. */
+int ppca_stats_raw(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_host);
+
+/* ------------------------------------------------ passes sharing the math */
+/* PPCAModel::llk :142-149 (weighted total) and llks :152-159 (per sample,
+ * unweighted; nullable; host or device destination). */
+int ppca_llk(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *total_host, double *per_sample_host);
+int ppca_llks_dev(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *per_sample_dev);
+/* PPCAModel::infer :221-227 -> InferredMasked.states (n x k) and covariances
+ * (n x k x k, nullable)  src/python_bindings.rs:211-234. */
+int ppca_infer(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *states_host, double *covs_host);
+/* PPCAModel::smooth :237-244 (mode 0) / extrapolate :254-261 (mode 1): a new,
+ * fully-unmasked dataset carrying the input weights (:259). */
+int ppca_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, int32_t mode, ppca_dataset **out);
+/* InferredMasked::smoothed_covariance_diagonal :485-508 (mode 0) and
+ * extrapolated_covariance_diagonal :542-577 (mode 1; observed dims -> 0). */
+int ppca_covariance_diagonal(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, int32_t mode,
+                             ppca_dataset **out);
+
+/* ---------------------------------------------------------------- mixture */
+/* PPCAMix::iterate_with_prior mix.rs:281-337 on one GPU: per-sample
+ * responsibilities (log-softmax of llk_c + log pi_c, :283-295), per-component
+ * weighted EM step (:297-330), new log-weights (:335).  models_in/out: n_models
+ * handles of equal (d, k).  llk_in (nullable): mixture log-likelihood of the input
+ * (PPCAMix::llk :162-174).  Samples with weight <= 0 contribute nothing
+ * (documented divergence from :304-309/:326). */
+int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models_in, const double *log_weights_in,
+                     int32_t n_models, const ppca_prior *prior, ppca_model *const *models_out,
+                     double *log_weights_out, double *llk_in);
+/* PPCAMix::llks :152-159 / llk :162-174 / infer_cluster :179-189 (log posteriors n x n_models). */
+int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
+                 int32_t n_models, double *total_host, double *per_sample_host, double *log_posteriors_host);
+
+/* ------------------------------------------------------------------ debug */
+/* One v_mfma_f64_16x16x4_f64 on host-supplied A (16 x 4) and B (4 x 16), result
+ * (16 x 16) written through the C/D lane map the kernels assume (unit test). */
+int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const double *b4x16, double *out16x16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPCA_HIP_H */

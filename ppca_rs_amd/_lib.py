@@ -1,0 +1,192 @@
+"""ctypes binding of libppca_hip.so (the C-ABI of include/ppca_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+present, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libppca_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+class PPCAError(RuntimeError):
+    """Raised for any non-zero ppca_status (the reference panics / raises)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[ppca_hip {code}] {message}")
+        self.code = code
+
+
+class Prior(C.Structure):
+    _fields_ = [
+        ("has_mean_prior", C.c_int32),
+        ("mean", c_double_p),
+        ("mean_covariance", c_double_p),
+        ("has_isotropic_noise_prior", C.c_int32),
+        ("isotropic_noise_alpha", C.c_double),
+        ("isotropic_noise_beta", C.c_double),
+        ("transformation_precision", C.c_double),
+    ]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [
+        ("row_offset", C.c_int64),
+        ("n_rows", C.c_int64),
+        ("d", C.c_int32),
+        ("k", C.c_int32),
+        ("sigma", C.c_double),
+        ("mask_prob", C.c_double),
+        ("mask_kind", C.c_int32),
+        ("mask_run", C.c_int32),
+        ("seed", C.c_uint64),
+        ("transform", c_double_p),
+        ("mean", c_double_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ppca_hip.h declares
+SIGNATURES = {
+    "ppca_last_error": (C.c_char_p, []),
+    "ppca_abi_version": (C.c_int32, []),
+    "ppca_path_kind": (C.c_int32, [C.c_int32, C.c_int32]),
+    "ppca_ctx_create": (C.c_int, [C.c_int32, C.c_void_p, c_void_pp]),
+    "ppca_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "ppca_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ppca_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "ppca_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ppca_ctx_kernel_time": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_int64), C.c_int32]),
+    "ppca_dataset_from_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, c_void_pp]),
+    "ppca_dataset_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, c_void_pp]),
+    "ppca_dataset_generate": (C.c_int, [C.c_void_p, C.POINTER(SynthSpec), c_void_pp]),
+    "ppca_dataset_with_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_void_pp]),
+    "ppca_dataset_slice": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_void_pp]),
+    "ppca_dataset_concat": (C.c_int, [C.c_void_p, c_void_pp, C.c_int32, c_void_pp]),
+    "ppca_dataset_free": (C.c_int, [C.c_void_p]),
+    "ppca_dataset_len": (C.c_int64, [C.c_void_p]),
+    "ppca_dataset_output_size": (C.c_int32, [C.c_void_p]),
+    "ppca_dataset_device_x": (C.c_void_p, [C.c_void_p]),
+    "ppca_dataset_device_weights": (C.c_void_p, [C.c_void_p]),
+    "ppca_dataset_to_host": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ppca_dataset_weights_to_host": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ppca_dataset_empty_dimensions": (C.c_int, [C.c_void_p, c_int32_p]),
+    "ppca_model_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, c_void_pp]),
+    "ppca_model_alloc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_void_pp]),
+    "ppca_model_download": (C.c_int, [C.c_void_p, c_double_p, C.c_void_p, C.c_void_p]),
+    "ppca_model_free": (C.c_int, [C.c_void_p]),
+    "ppca_model_output_size": (C.c_int32, [C.c_void_p]),
+    "ppca_model_state_size": (C.c_int32, [C.c_void_p]),
+    "ppca_stats_len": (C.c_int64, [C.c_int32, C.c_int32]),
+    "ppca_em_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppca_em_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), C.c_void_p]),
+    "ppca_em_finalize_host": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), c_double_p, C.c_void_p, C.c_void_p]),
+    "ppca_em_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), C.c_void_p, c_double_p]),
+    "ppca_stats_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppca_llk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_double_p, C.c_void_p]),
+    "ppca_llks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppca_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppca_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_void_pp]),
+    "ppca_covariance_diagonal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_void_pp]),
+    "ppca_mix_em_step": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, C.POINTER(Prior), c_void_pp, C.c_void_p, c_double_p]),
+    "ppca_mix_llk": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, c_double_p, C.c_void_p, C.c_void_p]),
+    "ppca_debug_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded shared library (raises ImportError loudly when it was not built)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        f"{LIB_PATH} is missing: build the HIP extension with `python -m ppca_rs_amd.build` "
+                        "(there is no CPU fallback)"
+                    )
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().ppca_last_error()
+        raise PPCAError(rc, msg.decode() if msg else "unknown error")
+
+
+def f64(x, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One GPU + one stream (ppca_ctx)."""
+
+    def __init__(self, device: int = -1, stream: int | None = None):
+        h = C.c_void_p()
+        check(lib().ppca_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+
+    def set_stream(self, stream: int | None) -> None:
+        check(lib().ppca_ctx_set_stream(self.handle, C.c_void_p(stream) if stream else None))
+
+    def synchronize(self) -> None:
+        check(lib().ppca_ctx_synchronize(self.handle))
+
+    def enable_timing(self, on: bool) -> None:
+        check(lib().ppca_ctx_enable_timing(self.handle, int(on)))
+
+    def kernel_time(self, reset: bool = True):
+        ms = C.c_double(0.0)
+        n = C.c_int64(0)
+        check(lib().ppca_ctx_kernel_time(self.handle, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.ppca_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    """Process-wide context on LOCAL_RANK's GPU (one process per GPU)."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("LOCAL_RANK", os.environ.get("PPCA_DEVICE", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx
+
+
+def set_default_context(ctx: Context) -> None:
+    global _default_ctx
+    _default_ctx = ctx

@@ -1,0 +1,950 @@
+// ppca_capi.hip -- host side of the C-ABI declared in include/ppca_hip.h.
+// Owns device memory behind opaque handles, sequences the kernels of
+// ppca_kernels.hip on the context stream and never computes the hot path on the
+// CPU: without a HIP device every compute entry point fails with PPCA_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ppca_hip.h"
+#include "ppca_internal.hpp"
+
+using namespace ppca;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(PPCA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------ handles
+struct DevBuf {
+    void *p = nullptr;
+    bool owned = true;
+    int device = 0;
+    ~DevBuf() {
+        if (p && owned) (void)hipFree(p);
+    }
+};
+typedef std::shared_ptr<DevBuf> BufRef;
+
+static int dev_alloc(size_t bytes, BufRef *out) {
+    auto b = std::make_shared<DevBuf>();
+    if (bytes == 0) bytes = 8;
+    HIP_TRY(hipMalloc(&b->p, bytes));
+    *out = b;
+    return PPCA_OK;
+}
+static BufRef dev_borrow(const void *p) {
+    auto b = std::make_shared<DevBuf>();
+    b->p = const_cast<void *>(p);
+    b->owned = false;
+    return b;
+}
+
+struct ppca_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    BufRef part;  // per-workgroup partial statistics
+    size_t part_cap = 0;
+    BufRef stats;  // scratch statistics buffer (em_step, stats_raw)
+    size_t stats_cap = 0;
+    BufRef scal;  // post-pass scalars: [grid][8] partials + 8 reduced
+    size_t scal_cap = 0;
+    BufRef work;  // 2048 doubles for reductions
+};
+
+struct ppca_dataset {
+    ppca_ctx *ctx = nullptr;
+    BufRef xbuf, wbuf;
+    const double *X = nullptr;
+    const double *w = nullptr;  // nullptr = all ones
+    int64_t n = 0;
+    int d = 0;
+};
+
+struct ppca_model {
+    ppca_ctx *ctx = nullptr;
+    int d = 0, k = 0;
+    BufRef buf;
+    double *p() const { return static_cast<double *>(buf->p); }
+};
+
+static int ensure(BufRef &b, size_t &cap, size_t bytes) {
+    if (cap >= bytes && b) return PPCA_OK;
+    BufRef nb;
+    int rc = dev_alloc(bytes, &nb);
+    if (rc) return rc;
+    b = nb;
+    cap = bytes;
+    return PPCA_OK;
+}
+
+static int use_device(const ppca_ctx *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return PPCA_OK;
+}
+
+// ------------------------------------------------------------------ misc
+extern "C" const char *ppca_last_error(void) { return g_err.c_str(); }
+extern "C" int32_t ppca_abi_version(void) { return PPCA_ABI_VERSION; }
+extern "C" int32_t ppca_path_kind(int32_t d, int32_t k) {
+    if (d < 1 || k < 1) return PPCA_ERR_INVALID;
+    if (d <= FUSED_MAX_D && k <= FUSED_MAX_K) return 1;
+    return PPCA_ERR_UNSUPPORTED;
+}
+
+static int check_path(int d, int k) {
+    int kind = ppca_path_kind(d, k);
+    if (kind == PPCA_ERR_INVALID) return fail(PPCA_ERR_INVALID, "invalid shape d=%d k=%d", d, k);
+    if (kind < 0)
+        return fail(PPCA_ERR_UNSUPPORTED, "shape d=%d k=%d is outside the fused kernel (d <= %d, k <= %d)", d, k,
+                    FUSED_MAX_D, FUSED_MAX_K);
+    return PPCA_OK;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int ppca_ctx_create(int32_t device_id, void *stream, ppca_ctx **out) {
+    if (!out) return fail(PPCA_ERR_INVALID, "out is null");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(PPCA_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    int dev = device_id;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= count) return fail(PPCA_ERR_INVALID, "device %d out of range (%d devices)", dev, count);
+    HIP_TRY(hipSetDevice(dev));
+    auto *ctx = new ppca_ctx();
+    ctx->device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (stream) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return fail(PPCA_ERR_HIP, "hipStreamCreate failed");
+        }
+        ctx->own_stream = true;
+    }
+    size_t cap = 0;
+    if (ensure(ctx->work, cap, 2048 * sizeof(double))) {
+        delete ctx;
+        return PPCA_ERR_HIP;
+    }
+    *out = ctx;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_ctx_destroy(ppca_ctx *ctx) {
+    if (!ctx) return PPCA_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_ctx_set_stream(ppca_ctx *ctx, void *stream) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) {
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    if (stream) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return PPCA_OK;
+}
+
+extern "C" int ppca_ctx_synchronize(ppca_ctx *ctx) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
+extern "C" int ppca_ctx_enable_timing(ppca_ctx *ctx, int32_t enabled) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
+    ctx->timing = enabled != 0;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_ctx_kernel_time(ppca_ctx *ctx, double *total_ms, int64_t *launches, int32_t reset) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (auto &ev : ctx->events) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)ctx->events.size();
+    if (reset) {
+        for (auto &ev : ctx->events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        ctx->events.clear();
+    }
+    return PPCA_OK;
+}
+
+// ------------------------------------------------------------------ dataset
+extern "C" int ppca_dataset_from_host(ppca_ctx *ctx, const double *x, int64_t n, int32_t d, int64_t row_stride,
+                                      int64_t col_stride, const double *weights, ppca_dataset **out) {
+    if (!ctx || !out || n < 0 || d < 1 || (n > 0 && !x)) return fail(PPCA_ERR_INVALID, "bad dataset arguments");
+    if (int rc = use_device(ctx)) return rc;
+    auto ds = std::make_unique<ppca_dataset>();
+    ds->ctx = ctx;
+    ds->n = n;
+    ds->d = d;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)n * d, &ds->xbuf)) return rc;
+    ds->X = static_cast<const double *>(ds->xbuf->p);
+    if (n > 0) {
+        if (col_stride == 1 && row_stride == d) {
+            HIP_TRY(hipMemcpyAsync(ds->xbuf->p, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            // arbitrary numpy view (src/python_bindings.rs:45): pack in chunks of rows
+            const int64_t chunk = std::max<int64_t>(1, (int64_t)(1 << 22) / d);
+            std::vector<double> stage((size_t)chunk * d);
+            for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+                int64_t rows = std::min(chunk, n - r0);
+                for (int64_t r = 0; r < rows; ++r)
+                    for (int j = 0; j < d; ++j) stage[(size_t)r * d + j] = x[(r0 + r) * row_stride + j * col_stride];
+                HIP_TRY(hipMemcpyAsync(static_cast<double *>(ds->xbuf->p) + r0 * d, stage.data(),
+                                       sizeof(double) * (size_t)rows * d, hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+            }
+        }
+    }
+    if (weights) {
+        if (int rc = dev_alloc(sizeof(double) * (size_t)n, &ds->wbuf)) return rc;
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync(ds->wbuf->p, weights, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        ds->w = static_cast<const double *>(ds->wbuf->p);
+    }
+    *out = ds.release();
+    return PPCA_OK;
+}
+
+extern "C" int ppca_dataset_from_device(ppca_ctx *ctx, const double *x_dev, int64_t n, int32_t d,
+                                        const double *weights_dev, ppca_dataset **out) {
+    if (!ctx || !out || n < 0 || d < 1 || (n > 0 && !x_dev)) return fail(PPCA_ERR_INVALID, "bad dataset arguments");
+    auto ds = std::make_unique<ppca_dataset>();
+    ds->ctx = ctx;
+    ds->n = n;
+    ds->d = d;
+    ds->xbuf = dev_borrow(x_dev);
+    ds->X = x_dev;
+    if (weights_dev) {
+        ds->wbuf = dev_borrow(weights_dev);
+        ds->w = weights_dev;
+    }
+    *out = ds.release();
+    return PPCA_OK;
+}
+
+extern "C" int ppca_dataset_generate(ppca_ctx *ctx, const ppca_synth_spec *spec, ppca_dataset **out) {
+    if (!ctx || !spec || !out) return fail(PPCA_ERR_INVALID, "null argument");
+    if (spec->n_rows < 0 || spec->d < 1 || spec->k < 0 || !spec->transform || !spec->mean)
+        return fail(PPCA_ERR_INVALID, "bad synth spec");
+    if (spec->mask_kind == 0 && !(spec->mask_prob >= 0.0 && spec->mask_prob <= 1.0))
+        return fail(PPCA_ERR_INVALID, "invalid mask probability");  // ppca_model.rs:171
+    if (int rc = use_device(ctx)) return rc;
+    const int d = spec->d, k = spec->k;
+    const int64_t n = spec->n_rows;
+    auto ds = std::make_unique<ppca_dataset>();
+    ds->ctx = ctx;
+    ds->n = n;
+    ds->d = d;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)n * d, &ds->xbuf)) return rc;
+    ds->X = static_cast<const double *>(ds->xbuf->p);
+    BufRef cbuf, zbuf;
+    if (int rc = dev_alloc(sizeof(double) * ((size_t)d * k + d), &cbuf)) return rc;
+    double *cdev = static_cast<double *>(cbuf->p);
+    double *mdev = cdev + (size_t)d * k;
+    if (k > 0) HIP_TRY(hipMemcpyAsync(cdev, spec->transform, sizeof(double) * (size_t)d * k, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(mdev, spec->mean, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
+    // generate in row chunks so the latent workspace stays small
+    const int64_t chunk = 1 << 20;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)std::min(chunk, std::max<int64_t>(n, 1)) * std::max(k, 1), &zbuf)) return rc;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        int64_t rows = std::min(chunk, n - r0);
+        HIP_TRY(launch_synth(cdev, mdev, static_cast<double *>(zbuf->p), static_cast<double *>(ds->xbuf->p) + r0 * d,
+                             spec->row_offset + r0, rows, d, k, spec->sigma, spec->mask_prob, spec->mask_kind,
+                             spec->mask_run, spec->seed, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = ds.release();
+    return PPCA_OK;
+}
+
+extern "C" int ppca_dataset_with_weights(ppca_dataset *ds, const double *weights_host, const double *weights_dev,
+                                         ppca_dataset **out) {
+    if (!ds || !out) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = use_device(ds->ctx)) return rc;
+    auto nd = std::make_unique<ppca_dataset>(*ds);
+    if (weights_dev) {
+        nd->wbuf = dev_borrow(weights_dev);
+        nd->w = weights_dev;
+    } else if (weights_host) {
+        if (int rc = dev_alloc(sizeof(double) * (size_t)ds->n, &nd->wbuf)) return rc;
+        if (ds->n > 0) {
+            HIP_TRY(hipMemcpyAsync(nd->wbuf->p, weights_host, sizeof(double) * (size_t)ds->n, hipMemcpyHostToDevice,
+                                   ds->ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ds->ctx->stream));
+        }
+        nd->w = static_cast<const double *>(nd->wbuf->p);
+    } else {
+        nd->wbuf.reset();
+        nd->w = nullptr;
+    }
+    *out = nd.release();
+    return PPCA_OK;
+}
+
+extern "C" int ppca_dataset_slice(ppca_dataset *ds, int64_t start, int64_t len, ppca_dataset **out) {
+    if (!ds || !out || start < 0 || len < 0 || start + len > ds->n) return fail(PPCA_ERR_INVALID, "bad slice");
+    auto nd = std::make_unique<ppca_dataset>(*ds);
+    nd->X = ds->X + start * ds->d;
+    nd->w = ds->w ? ds->w + start : nullptr;
+    nd->n = len;
+    *out = nd.release();
+    return PPCA_OK;
+}
+
+extern "C" int ppca_dataset_concat(ppca_ctx *ctx, ppca_dataset *const *parts, int32_t n_parts, ppca_dataset **out) {
+    if (!ctx || !out || n_parts < 0 || (n_parts > 0 && !parts)) return fail(PPCA_ERR_INVALID, "null argument");
+    if (n_parts == 0) return fail(PPCA_ERR_EMPTY, "cannot concatenate an empty list");
+    if (int rc = use_device(ctx)) return rc;
+    int64_t n = 0;
+    const int d = parts[0]->d;
+    for (int i = 0; i < n_parts; ++i) {
+        if (!parts[i] || parts[i]->d != d) return fail(PPCA_ERR_INVALID, "datasets have different output sizes");
+        n += parts[i]->n;
+    }
+    auto ds = std::make_unique<ppca_dataset>();
+    ds->ctx = ctx;
+    ds->n = n;
+    ds->d = d;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)n * d, &ds->xbuf)) return rc;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)n, &ds->wbuf)) return rc;
+    ds->X = static_cast<const double *>(ds->xbuf->p);
+    ds->w = static_cast<const double *>(ds->wbuf->p);
+    int64_t off = 0;
+    for (int i = 0; i < n_parts; ++i) {
+        const ppca_dataset *p = parts[i];
+        if (p->n == 0) continue;
+        HIP_TRY(hipMemcpyAsync(static_cast<double *>(ds->xbuf->p) + off * d, p->X, sizeof(double) * (size_t)p->n * d,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+        if (p->w) {
+            HIP_TRY(hipMemcpyAsync(static_cast<double *>(ds->wbuf->p) + off, p->w, sizeof(double) * (size_t)p->n,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            HIP_TRY(launch_fill(static_cast<double *>(ds->wbuf->p) + off, p->n, 1.0, ctx->stream));
+        }
+        off += p->n;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = ds.release();
+    return PPCA_OK;
+}
+
+extern "C" int ppca_dataset_free(ppca_dataset *ds) {
+    if (ds) {
+        (void)hipSetDevice(ds->ctx->device);
+        delete ds;
+    }
+    return PPCA_OK;
+}
+extern "C" int64_t ppca_dataset_len(const ppca_dataset *ds) { return ds ? ds->n : 0; }
+extern "C" int32_t ppca_dataset_output_size(const ppca_dataset *ds) { return ds ? ds->d : 0; }
+extern "C" const double *ppca_dataset_device_x(const ppca_dataset *ds) { return ds ? ds->X : nullptr; }
+extern "C" const double *ppca_dataset_device_weights(const ppca_dataset *ds) { return ds ? ds->w : nullptr; }
+
+extern "C" int ppca_dataset_to_host(ppca_dataset *ds, double *out) {
+    if (!ds || (!out && ds->n > 0)) return fail(PPCA_ERR_INVALID, "null argument");
+    if (ds->n == 0) return PPCA_OK;
+    if (int rc = use_device(ds->ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ds->ctx->stream));
+    HIP_TRY(hipMemcpy(out, ds->X, sizeof(double) * (size_t)ds->n * ds->d, hipMemcpyDeviceToHost));
+    // masked_vector (dataset.rs:64-72): masked -> NaN; +-inf inputs are masked, so they come back NaN too
+    const size_t tot = (size_t)ds->n * ds->d;
+    for (size_t i = 0; i < tot; ++i)
+        if (!std::isfinite(out[i])) out[i] = NAN;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_dataset_weights_to_host(ppca_dataset *ds, double *out) {
+    if (!ds || (!out && ds->n > 0)) return fail(PPCA_ERR_INVALID, "null argument");
+    if (ds->n == 0) return PPCA_OK;
+    if (!ds->w) {
+        for (int64_t i = 0; i < ds->n; ++i) out[i] = 1.0;
+        return PPCA_OK;
+    }
+    if (int rc = use_device(ds->ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ds->ctx->stream));
+    HIP_TRY(hipMemcpy(out, ds->w, sizeof(double) * (size_t)ds->n, hipMemcpyDeviceToHost));
+    return PPCA_OK;
+}
+
+extern "C" int ppca_dataset_empty_dimensions(ppca_dataset *ds, int32_t *flags) {
+    if (!ds || !flags) return fail(PPCA_ERR_INVALID, "null argument");
+    ppca_ctx *ctx = ds->ctx;
+    if (int rc = use_device(ctx)) return rc;
+    BufRef pres;
+    if (int rc = dev_alloc(sizeof(int) * (size_t)ds->d, &pres)) return rc;
+    HIP_TRY(hipMemsetAsync(pres->p, 0, sizeof(int) * (size_t)ds->d, ctx->stream));
+    HIP_TRY(launch_column_presence(ds->X, ds->d, ds->n, ds->d, static_cast<int *>(pres->p), ctx->stream));
+    std::vector<int> h(ds->d);
+    HIP_TRY(hipMemcpyAsync(h.data(), pres->p, sizeof(int) * (size_t)ds->d, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < ds->d; ++j) flags[j] = h[j] ? 0 : 1;
+    return PPCA_OK;
+}
+
+// ------------------------------------------------------------------ model
+extern "C" int ppca_model_alloc(ppca_ctx *ctx, int32_t d, int32_t k, ppca_model **out) {
+    if (!ctx || !out || d < 1 || k < 0) return fail(PPCA_ERR_INVALID, "bad model shape");
+    if (int rc = use_device(ctx)) return rc;
+    auto m = std::make_unique<ppca_model>();
+    m->ctx = ctx;
+    m->d = d;
+    m->k = k;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)model_len(d, k), &m->buf)) return rc;
+    *out = m.release();
+    return PPCA_OK;
+}
+
+extern "C" int ppca_model_create(ppca_ctx *ctx, int32_t d, int32_t k, double sigma, const double *transform,
+                                 const double *mean, ppca_model **out) {
+    if (!mean || (k > 0 && !transform)) return fail(PPCA_ERR_INVALID, "null model arrays");
+    ppca_model *m = nullptr;
+    if (int rc = ppca_model_alloc(ctx, d, k, &m)) return rc;
+    std::vector<double> h((size_t)model_len(d, k));
+    h[0] = sigma;
+    h[1] = sigma * sigma;  // isotropic_noise.powi(2), output_covariance.rs:62
+    h[2] = std::log(sigma);
+    h[3] = 0.0;
+    if (k > 0) std::memcpy(h.data() + MODEL_HDR, transform, sizeof(double) * (size_t)d * k);
+    std::memcpy(h.data() + MODEL_HDR + (size_t)d * k, mean, sizeof(double) * d);
+    hipError_t e = hipMemcpyAsync(m->p(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        delete m;
+        return fail(PPCA_ERR_HIP, "model upload failed: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_model_download(ppca_model *m, double *sigma, double *transform, double *mean) {
+    if (!m) return fail(PPCA_ERR_INVALID, "null model");
+    if (int rc = use_device(m->ctx)) return rc;
+    std::vector<double> h((size_t)model_len(m->d, m->k));
+    HIP_TRY(hipMemcpyAsync(h.data(), m->p(), sizeof(double) * h.size(), hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    if (sigma) *sigma = h[0];
+    if (transform && m->k > 0) std::memcpy(transform, h.data() + MODEL_HDR, sizeof(double) * (size_t)m->d * m->k);
+    if (mean) std::memcpy(mean, h.data() + MODEL_HDR + (size_t)m->d * m->k, sizeof(double) * m->d);
+    return PPCA_OK;
+}
+
+extern "C" int ppca_model_free(ppca_model *m) {
+    if (m) {
+        (void)hipSetDevice(m->ctx->device);
+        delete m;
+    }
+    return PPCA_OK;
+}
+extern "C" int32_t ppca_model_output_size(const ppca_model *m) { return m ? m->d : 0; }
+extern "C" int32_t ppca_model_state_size(const ppca_model *m) { return m ? m->k : 0; }
+
+// ------------------------------------------------------------------ EM step
+extern "C" int64_t ppca_stats_len(int32_t d, int32_t k) { return StatsLayout(d, k).len; }
+
+static int check_pair(const ppca_dataset *ds, const ppca_model *model) {
+    if (!ds || !model) return fail(PPCA_ERR_INVALID, "null dataset or model");
+    if (ds->d != model->d)  // assert_eq!(mask.0.len(), self.output_size()) output_covariance.rs:124
+        return fail(PPCA_ERR_INVALID, "dataset has %d dimensions but the model has output size %d", ds->d, model->d);
+    if (ds->ctx->device != model->ctx->device) return fail(PPCA_ERR_INVALID, "dataset and model live on different devices");
+    return check_path(model->d, model->k);
+}
+
+extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_dev) {
+    if (!ctx || !stats_dev) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_pair(ds, model)) return rc;
+    if (int rc = use_device(ctx)) return rc;
+    const StatsLayout L(model->d, model->k);
+    if (ds->n == 0) {
+        HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * (size_t)L.len, ctx->stream));
+        return PPCA_OK;
+    }
+    const int grid = fused_grid(ds->n, ctx->n_cu);
+    if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)grid * L.len)) return rc;
+    PassArgs a{};
+    a.X = ds->X;
+    a.ldx = ds->d;
+    a.w = ds->w;
+    a.n = ds->n;
+    a.d = ds->d;
+    a.model = model->p();
+    a.part = static_cast<double *>(ctx->part->p);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(launch_pass_em(model->k, grid, a, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        ctx->events.emplace_back(e0, e1);
+    }
+    HIP_TRY(launch_reduce_partials(a.part, grid, L.len, stats_dev, ctx->stream));
+    return PPCA_OK;
+}
+
+// Dense solve A x = b (n x n, row-major) by LU with partial pivoting; false if singular.
+static bool lu_solve(std::vector<double> a, int n, std::vector<double> &b) {
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        double best = std::fabs(a[(size_t)c * n + c]);
+        for (int r = c + 1; r < n; ++r)
+            if (std::fabs(a[(size_t)r * n + c]) > best) { best = std::fabs(a[(size_t)r * n + c]); p = r; }
+        if (!(best > 0.0)) return false;
+        if (p != c) {
+            for (int j = 0; j < n; ++j) std::swap(a[(size_t)c * n + j], a[(size_t)p * n + j]);
+            std::swap(b[c], b[p]);
+        }
+        for (int r = c + 1; r < n; ++r) {
+            double f = a[(size_t)r * n + c] / a[(size_t)c * n + c];
+            if (f == 0.0) continue;
+            for (int j = c; j < n; ++j) a[(size_t)r * n + j] -= f * a[(size_t)c * n + j];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = n - 1; r >= 0; --r) {
+        double s = b[r];
+        for (int j = r + 1; j < n; ++j) s -= a[(size_t)r * n + j] * b[j];
+        b[r] = s / a[(size_t)r * n + r];
+    }
+    return true;
+}
+
+// Prior::smooth_mean prior.rs:97-110 with precision = diag(totals) / sigma^2 (ppca_model.rs:379-384)
+static int smooth_mean_host(const ppca_prior *prior, int d, const double *totals, double s2, double *mean) {
+    const size_t dd = (size_t)d * d;
+    // prior precision = inverse of the prior covariance (prior.rs:36-41)
+    std::vector<double> prec(dd);
+    for (int c = 0; c < d; ++c) {
+        std::vector<double> e(d, 0.0);
+        e[c] = 1.0;
+        if (!lu_solve(std::vector<double>(prior->mean_covariance, prior->mean_covariance + dd), d, e))
+            return fail(PPCA_ERR_NUMERIC, "mean covariance should be invertible");
+        for (int r = 0; r < d; ++r) prec[(size_t)r * d + c] = e[r];
+    }
+    std::vector<double> tot(prec), num(d);
+    for (int i = 0; i < d; ++i) {
+        const double pd = totals[i] / s2;
+        tot[(size_t)i * d + i] += pd;
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) s += prec[(size_t)i * d + j] * prior->mean[j];
+        num[i] = s + pd * mean[i];
+    }
+    if (!lu_solve(tot, d, num)) return fail(PPCA_ERR_NUMERIC, "total precision matrix is not invertible");
+    std::memcpy(mean, num.data(), sizeof(double) * d);
+    return PPCA_OK;
+}
+
+static int check_prior(const ppca_prior *prior) {
+    if (!prior) return PPCA_OK;
+    if (prior->has_isotropic_noise_prior && !(prior->isotropic_noise_alpha >= 0.0 && prior->isotropic_noise_beta >= 0.0))
+        return fail(PPCA_ERR_INVALID, "isotropic noise prior needs alpha >= 0 and beta >= 0");  // prior.rs:50-51
+    if (!(prior->transformation_precision >= 0.0))
+        return fail(PPCA_ERR_INVALID, "transformation precision must be >= 0");  // prior.rs:61
+    if (prior->has_mean_prior && (!prior->mean || !prior->mean_covariance))
+        return fail(PPCA_ERR_INVALID, "mean prior arrays are null");
+    return PPCA_OK;
+}
+
+extern "C" int ppca_em_finalize_host(int32_t d, int32_t k, double sigma, const double *transform, const double *mean,
+                                     const double *stats, const ppca_prior *prior, double *sigma_out,
+                                     double *transform_out, double *mean_out) {
+    if (d < 1 || k < 0 || !mean || !stats || !sigma_out || !mean_out || (k > 0 && (!transform || !transform_out)))
+        return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_prior(prior)) return rc;
+    (void)sigma;
+    const StatsLayout L(d, k);
+    const double tau = prior ? prior->transformation_precision : 0.0;
+    double totsum = 0.0;
+    for (int j = 0; j < d; ++j) totsum += stats[L.totals + j];
+    const double sq = stats[L.scalars + SC_SQERR], dv = stats[L.scalars + SC_DEVSQ];
+    const double s2new = (prior && prior->has_isotropic_noise_prior)
+                             ? ((sq + dv) / 2.0 + prior->isotropic_noise_beta) /
+                                   (totsum / 2.0 + prior->isotropic_noise_alpha + 1.0)
+                             : (sq + dv) / totsum;
+    std::vector<double> S((size_t)L.kp + 1), x((size_t)k + 1);
+    for (int j = 0; j < d; ++j) {
+        for (int e = 0; e < L.kp; ++e) S[e] = stats[L.S + (int64_t)j * L.kp + e];
+        for (int a = 0; a < k; ++a) S[tri(a, a)] += tau;
+        double cz = 0.0;
+        for (int a = 0; a < k; ++a) {
+            x[a] = stats[L.cross + (int64_t)j * k + a];
+            cz += transform[(int64_t)j * k + a] * stats[L.U + (int64_t)j * k + a];
+        }
+        if (chol_packed(S.data(), k)) {
+            chol_solve_packed(S.data(), k, x.data());
+            for (int a = 0; a < k; ++a) transform_out[(int64_t)j * k + a] = x[a];
+        } else {
+            for (int a = 0; a < k; ++a) transform_out[(int64_t)j * k + a] = transform[(int64_t)j * k + a];
+        }
+        const double tot = stats[L.totals + j];
+        mean_out[j] = (tot > 0.0 ? (stats[L.sumx + j] - cz) / tot : 0.0) + mean[j];
+    }
+    if (prior && prior->has_mean_prior) {
+        if (int rc = smooth_mean_host(prior, d, stats + L.totals, s2new, mean_out)) return rc;
+    }
+    *sigma_out = std::sqrt(s2new);
+    return PPCA_OK;
+}
+
+extern "C" int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const double *stats_dev,
+                                const ppca_prior *prior, ppca_model *out) {
+    if (!ctx || !model_in || !stats_dev || !out) return fail(PPCA_ERR_INVALID, "null argument");
+    if (out == model_in || out->buf == model_in->buf) return fail(PPCA_ERR_INVALID, "out may not alias model_in");
+    if (out->d != model_in->d || out->k != model_in->k) return fail(PPCA_ERR_INVALID, "model shapes differ");
+    if (int rc = check_path(model_in->d, model_in->k)) return rc;
+    if (int rc = check_prior(prior)) return rc;
+    if (int rc = use_device(ctx)) return rc;
+    const int d = model_in->d, k = model_in->k;
+    const double tau = prior ? prior->transformation_precision : 0.0;
+    const int has_ig = prior ? prior->has_isotropic_noise_prior : 0;
+    HIP_TRY(launch_finalize(k, d, stats_dev, model_in->p(), out->p(), tau, has_ig,
+                            has_ig ? prior->isotropic_noise_alpha : 0.0, has_ig ? prior->isotropic_noise_beta : 0.0,
+                            ctx->stream));
+    if (prior && prior->has_mean_prior) {
+        // rare branch (d x d solve, prior.rs:97-110): host round trip
+        const StatsLayout L(d, k);
+        std::vector<double> totals(d), hdr(MODEL_HDR), mean(d);
+        HIP_TRY(hipMemcpyAsync(totals.data(), stats_dev + L.totals, sizeof(double) * d, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(hdr.data(), out->p(), sizeof(double) * MODEL_HDR, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(mean.data(), out->p() + MODEL_HDR + (size_t)d * k, sizeof(double) * d, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        // isotropic_noise_sq as used at ppca_model.rs:382 is the un-rounded variance; hdr[1] = sigma*sigma differs by <= 1 ulp
+        if (int rc = smooth_mean_host(prior, d, totals.data(), hdr[1], mean.data())) return rc;
+        HIP_TRY(hipMemcpyAsync(out->p() + MODEL_HDR + (size_t)d * k, mean.data(), sizeof(double) * d, hipMemcpyHostToDevice,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return PPCA_OK;
+}
+
+extern "C" int ppca_em_step(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model_in, const ppca_prior *prior,
+                            ppca_model *out, double *llk_in) {
+    if (!ctx || !out) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_pair(ds, model_in)) return rc;
+    if (ds->n == 0) return fail(PPCA_ERR_EMPTY, "dataset is empty");
+    const StatsLayout L(model_in->d, model_in->k);
+    if (int rc = ensure(ctx->stats, ctx->stats_cap, sizeof(double) * (size_t)L.len)) return rc;
+    double *stats = static_cast<double *>(ctx->stats->p);
+    if (int rc = ppca_em_accumulate(ctx, ds, model_in, stats)) return rc;
+    if (int rc = ppca_em_finalize(ctx, model_in, stats, prior, out)) return rc;
+    if (llk_in) {
+        HIP_TRY(hipMemcpyAsync(llk_in, stats + L.scalars + SC_LLK, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return PPCA_OK;
+}
+
+extern "C" int ppca_stats_raw(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_host) {
+    if (!ctx || !stats_host) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_pair(ds, model)) return rc;
+    const StatsLayout L(model->d, model->k);
+    if (int rc = ensure(ctx->stats, ctx->stats_cap, sizeof(double) * (size_t)L.len)) return rc;
+    double *stats = static_cast<double *>(ctx->stats->p);
+    if (int rc = ppca_em_accumulate(ctx, ds, model, stats)) return rc;
+    HIP_TRY(hipMemcpyAsync(stats_host, stats, sizeof(double) * (size_t)L.len, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
+// ------------------------------------------------------------------ post passes
+// Runs pass_kernel<K, false>; scalars (if wanted) end up in ctx->scal[grid*8 .. grid*8+8).
+static int run_post(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *llks_dev, double *states_dev,
+                    double *covs_dev, double *recon_dev, int recon_mode, double **scal_out) {
+    if (int rc = use_device(ctx)) return rc;
+    const int grid = fused_grid(ds->n, ctx->n_cu);
+    if (int rc = ensure(ctx->scal, ctx->scal_cap, sizeof(double) * ((size_t)grid * 8 + 8))) return rc;
+    double *scal = static_cast<double *>(ctx->scal->p);
+    if (ds->n == 0) {
+        HIP_TRY(hipMemsetAsync(scal + (size_t)grid * 8, 0, sizeof(double) * 8, ctx->stream));
+    } else {
+        PassArgs a{};
+        a.X = ds->X;
+        a.ldx = ds->d;
+        a.w = ds->w;
+        a.n = ds->n;
+        a.d = ds->d;
+        a.model = model->p();
+        a.scal_part = scal;
+        a.llks = llks_dev;
+        a.states = states_dev;
+        a.covs = covs_dev;
+        a.recon = recon_dev;
+        a.recon_mode = recon_mode;
+        HIP_TRY(launch_pass_post(model->k, grid, a, ctx->stream));
+        HIP_TRY(launch_reduce_partials(scal, grid, 8, scal + (size_t)grid * 8, ctx->stream));
+    }
+    if (scal_out) *scal_out = scal + (size_t)grid * 8;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_llks_dev(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *per_sample_dev) {
+    if (!ctx || !per_sample_dev) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_pair(ds, model)) return rc;
+    return run_post(ctx, ds, model, per_sample_dev, nullptr, nullptr, nullptr, 0, nullptr);
+}
+
+extern "C" int ppca_llk(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *total_host,
+                        double *per_sample_host) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_pair(ds, model)) return rc;
+    if (int rc = use_device(ctx)) return rc;
+    BufRef l;
+    if (per_sample_host)
+        if (int rc = dev_alloc(sizeof(double) * (size_t)ds->n, &l)) return rc;
+    double *scal = nullptr;
+    if (int rc = run_post(ctx, ds, model, l ? static_cast<double *>(l->p) : nullptr, nullptr, nullptr, nullptr, 0, &scal))
+        return rc;
+    double h[8];
+    HIP_TRY(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    if (per_sample_host && ds->n > 0)
+        HIP_TRY(hipMemcpyAsync(per_sample_host, l->p, sizeof(double) * (size_t)ds->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (total_host) *total_host = h[SC_LLK];
+    return PPCA_OK;
+}
+
+extern "C" int ppca_infer(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *states_host,
+                          double *covs_host) {
+    if (!ctx || !states_host) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_pair(ds, model)) return rc;
+    if (int rc = use_device(ctx)) return rc;
+    const int k = model->k;
+    BufRef st, cv;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)ds->n * k, &st)) return rc;
+    if (covs_host)
+        if (int rc = dev_alloc(sizeof(double) * (size_t)ds->n * k * k, &cv)) return rc;
+    if (int rc = run_post(ctx, ds, model, nullptr, static_cast<double *>(st->p), cv ? static_cast<double *>(cv->p) : nullptr,
+                          nullptr, 0, nullptr))
+        return rc;
+    if (ds->n > 0) {
+        HIP_TRY(hipMemcpyAsync(states_host, st->p, sizeof(double) * (size_t)ds->n * k, hipMemcpyDeviceToHost, ctx->stream));
+        if (covs_host)
+            HIP_TRY(hipMemcpyAsync(covs_host, cv->p, sizeof(double) * (size_t)ds->n * k * k, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
+static int recon_common(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, int mode, ppca_dataset **out) {
+    if (!ctx || !out) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_pair(ds, model)) return rc;
+    if (int rc = use_device(ctx)) return rc;
+    auto nd = std::make_unique<ppca_dataset>();
+    nd->ctx = ctx;
+    nd->n = ds->n;
+    nd->d = ds->d;
+    nd->wbuf = ds->wbuf;  // weights carried over (ppca_model.rs:242, :259)
+    nd->w = ds->w;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)ds->n * ds->d, &nd->xbuf)) return rc;
+    nd->X = static_cast<const double *>(nd->xbuf->p);
+    if (int rc = run_post(ctx, ds, model, nullptr, nullptr, nullptr, static_cast<double *>(nd->xbuf->p), mode, nullptr))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = nd.release();
+    return PPCA_OK;
+}
+
+extern "C" int ppca_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, int32_t mode,
+                                ppca_dataset **out) {
+    if (mode != 0 && mode != 1) return fail(PPCA_ERR_INVALID, "mode must be 0 (smooth) or 1 (extrapolate)");
+    return recon_common(ctx, ds, model, mode, out);
+}
+
+extern "C" int ppca_covariance_diagonal(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, int32_t mode,
+                                        ppca_dataset **out) {
+    if (mode != 0 && mode != 1) return fail(PPCA_ERR_INVALID, "mode must be 0 (smoothed) or 1 (extrapolated)");
+    return recon_common(ctx, ds, model, 2 + mode, out);
+}
+
+// ------------------------------------------------------------------ mixture
+static int mix_check(ppca_dataset *ds, ppca_model *const *models, int32_t nm) {
+    if (!ds || !models || nm < 1) return fail(PPCA_ERR_INVALID, "bad mixture arguments");
+    for (int c = 0; c < nm; ++c) {
+        if (int rc = check_pair(ds, models[c])) return rc;
+        if (models[c]->k != models[0]->k)
+            return fail(PPCA_ERR_UNSUPPORTED, "mixture components must share one state size");
+    }
+    return PPCA_OK;
+}
+
+// llks of every component -> llk[nm][n]; posteriors/lse on device.
+static int mix_posteriors(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
+                          int32_t nm, BufRef &llk, BufRef &u, BufRef &lse, BufRef *logpost) {
+    const int64_t n = ds->n;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)nm * n, &llk)) return rc;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)nm * n, &u)) return rc;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)n, &lse)) return rc;
+    if (logpost)
+        if (int rc = dev_alloc(sizeof(double) * (size_t)nm * n, logpost)) return rc;
+    for (int c = 0; c < nm; ++c)
+        if (int rc = ppca_llks_dev(ctx, ds, models[c], static_cast<double *>(llk->p) + (size_t)c * n)) return rc;
+    // normalised log-weights (PPCAMix::new mix.rs:66-70)
+    std::vector<double> lw(log_weights, log_weights + nm);
+    double mx = lw[0];
+    for (double v : lw) mx = std::max(mx, v);
+    double s = 0.0;
+    for (double v : lw) s += std::exp(v - mx);
+    for (double &v : lw) v = v - mx - std::log(s);
+    double *work = static_cast<double *>(ctx->work->p);
+    HIP_TRY(hipMemcpyAsync(work + 1536, lw.data(), sizeof(double) * nm, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(launch_mix_posteriors(static_cast<double *>(llk->p), work + 1536, ds->w, n, nm, static_cast<double *>(u->p),
+                                  static_cast<double *>(lse->p), logpost ? static_cast<double *>((*logpost)->p) : nullptr,
+                                  ctx->stream));
+    return PPCA_OK;
+}
+
+extern "C" int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
+                            int32_t n_models, double *total_host, double *per_sample_host, double *log_posteriors_host) {
+    if (!ctx || !log_weights) return fail(PPCA_ERR_INVALID, "null argument");
+    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
+    if (int rc = mix_check(ds, models, n_models)) return rc;
+    if (int rc = use_device(ctx)) return rc;
+    const int64_t n = ds->n;
+    if (n == 0) {  // mix.rs:164-166
+        if (total_host) *total_host = 0.0;
+        return PPCA_OK;
+    }
+    BufRef llk, u, lse, lp;
+    if (int rc = mix_posteriors(ctx, ds, models, log_weights, n_models, llk, u, lse, log_posteriors_host ? &lp : nullptr))
+        return rc;
+    double *work = static_cast<double *>(ctx->work->p);
+    HIP_TRY(launch_reduce_sum(static_cast<double *>(lse->p), ds->w, n, work + 1024, work, ctx->stream));
+    double tot = 0.0;
+    HIP_TRY(hipMemcpyAsync(&tot, work + 1024, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (per_sample_host)
+        HIP_TRY(hipMemcpyAsync(per_sample_host, lse->p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (log_posteriors_host)
+        HIP_TRY(hipMemcpyAsync(log_posteriors_host, lp->p, sizeof(double) * (size_t)n * n_models, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (total_host) *total_host = tot;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models_in,
+                                const double *log_weights_in, int32_t n_models, const ppca_prior *prior,
+                                ppca_model *const *models_out, double *log_weights_out, double *llk_in) {
+    if (!ctx || !log_weights_in || !models_out || !log_weights_out) return fail(PPCA_ERR_INVALID, "null argument");
+    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
+    if (int rc = mix_check(ds, models_in, n_models)) return rc;
+    if (ds->n == 0) return fail(PPCA_ERR_EMPTY, "dataset is empty");
+    if (int rc = use_device(ctx)) return rc;
+    const int64_t n = ds->n;
+    const int nm = n_models;
+    BufRef llk, u, lse;
+    if (int rc = mix_posteriors(ctx, ds, models_in, log_weights_in, nm, llk, u, lse, nullptr)) return rc;
+    double *work = static_cast<double *>(ctx->work->p);
+    if (llk_in) {
+        HIP_TRY(launch_reduce_sum(static_cast<double *>(lse->p), ds->w, n, work + 1024, work, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(llk_in, work + 1024, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    BufRef wc;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)n, &wc)) return rc;
+    std::vector<double> logsum(nm);
+    for (int c = 0; c < nm; ++c) {
+        const double *uc = static_cast<double *>(u->p) + (size_t)c * n;
+        // max (mix.rs:312-317), unnormalised posteriors (:320-323), log-sum (:324-325)
+        HIP_TRY(launch_reduce_max(uc, n, work + 1025, work, ctx->stream));
+        HIP_TRY(launch_exp_shift(uc, work + 1025, n, static_cast<double *>(wc->p), ctx->stream));
+        HIP_TRY(launch_reduce_sum(static_cast<double *>(wc->p), nullptr, n, work + 1026, work, ctx->stream));
+        double h[2];
+        HIP_TRY(hipMemcpyAsync(h, work + 1025, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        logsum[c] = std::log(h[1]) + h[0];
+        ppca_dataset *wds = nullptr;
+        if (int rc = ppca_dataset_with_weights(ds, nullptr, static_cast<double *>(wc->p), &wds)) return rc;
+        int rc = ppca_em_step(ctx, wds, models_in[c], prior, models_out[c], nullptr);  // :326-328
+        if (rc == PPCA_OK) rc = ppca_ctx_synchronize(ctx);
+        ppca_dataset_free(wds);
+        if (rc) return rc;
+    }
+    // :335 robust_log_softmax
+    double mx = logsum[0];
+    for (double v : logsum) mx = std::max(mx, v);
+    double s = 0.0;
+    for (double v : logsum) s += std::exp(v - mx);
+    for (int c = 0; c < nm; ++c) log_weights_out[c] = logsum[c] - mx - std::log(s);
+    return PPCA_OK;
+}
+
+// ------------------------------------------------------------------ debug
+extern "C" int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const double *b4x16, double *out16x16) {
+    if (!ctx || !a16x4 || !b4x16 || !out16x16) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = use_device(ctx)) return rc;
+    BufRef buf;
+    if (int rc = dev_alloc(sizeof(double) * (64 + 64 + 256), &buf)) return rc;
+    double *p = static_cast<double *>(buf->p);
+    HIP_TRY(hipMemcpyAsync(p, a16x4, sizeof(double) * 64, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(p + 64, b4x16, sizeof(double) * 64, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_mfma_probe(p, p + 64, p + 128, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out16x16, p + 128, sizeof(double) * 256, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}

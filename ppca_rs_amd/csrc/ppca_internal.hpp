@@ -1,0 +1,69 @@
+// ppca_internal.hpp -- declarations shared by the kernels (ppca_kernels.hip) and
+// the C-ABI host layer (ppca_capi.hip).  Not installed; the public surface is
+// include/ppca_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ppca_small.hpp"
+
+namespace ppca {
+
+// Device model buffer: [sigma, sigma^2, ln sigma, 0 | C (d x k row-major) | mean (d)]
+constexpr int MODEL_HDR = 4;
+inline int64_t model_len(int d, int k) { return MODEL_HDR + (int64_t)d * k + d; }
+
+constexpr int FUSED_MAX_D = 256;  // one LDS-resident tile of 32 samples x 256 dims
+constexpr int FUSED_MAX_K = 10;   // k(k+1)/2 + k + 1 <= 80 accumulator columns
+constexpr int FUSED_TILE = 32;    // samples per tile
+constexpr int FUSED_THREADS = 256;
+
+struct PassArgs {
+    const double *X;      // n x d row-major, non-finite = masked
+    int64_t ldx;          // row stride in elements
+    const double *w;      // n weights or nullptr (= 1)
+    int64_t n;
+    int d;
+    const double *model;  // device model buffer
+    // EM mode
+    double *part;         // [grid][stats_len] per-workgroup partial statistics
+    // post mode (all nullable)
+    double *scal_part;    // [grid][8] per-workgroup scalars (llk, sumw, ...)
+    double *llks;         // n
+    double *states;       // n x k
+    double *covs;         // n x k x k
+    double *recon;        // n x d
+    int recon_mode;       // 0 smooth, 1 extrapolate, 2 smoothed cov diag, 3 extrapolated cov diag
+};
+
+// Number of workgroups the fused pass wants for n rows on a device with n_cu CUs.
+int fused_grid(int64_t n, int n_cu);
+size_t fused_lds_bytes(int k);
+// Launchers.  Return hipSuccess or the launch error.
+hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s);
+hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);
+hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s);
+hipError_t launch_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
+                           int has_ig, double alpha, double beta, hipStream_t s);
+hipError_t launch_synth(const double *c_dev, const double *mean_dev, double *z_work, double *x_out, int64_t row_offset,
+                        int64_t n_rows, int d, int k, double sigma, double mask_prob, int mask_kind, int mask_run,
+                        uint64_t seed, hipStream_t s);
+hipError_t launch_column_presence(const double *X, int64_t ldx, int64_t n, int d, int *present, hipStream_t s);
+hipError_t launch_fill(double *p, int64_t n, double v, hipStream_t s);
+// debug: C/D layout probe of v_mfma_f64_16x16x4_f64 (out: 16 x 16 row-major)
+hipError_t launch_mfma_probe(const double *a16x4, const double *b4x16, double *out16x16, hipStream_t s);
+
+// mixture helpers
+// llk: [n_models][n]; logw: [n_models]; w nullable.  Writes u: [n_models][n] =
+// ln w_i + log posterior_ic (-inf when w_i <= 0) and lse[n] (mixture llk per sample).
+hipError_t launch_mix_posteriors(const double *llk, const double *logw_dev, const double *w, int64_t n, int nm,
+                                 double *u, double *lse, double *logpost, hipStream_t s);
+hipError_t launch_reduce_max(const double *v, int64_t n, double *out_scalar, double *work, hipStream_t s);
+// out[i] = exp(v[i] - *max_dev)
+hipError_t launch_exp_shift(const double *v, const double *max_dev, int64_t n, double *out, hipStream_t s);
+hipError_t launch_reduce_sum(const double *v, const double *w, int64_t n, double *out_scalar, double *work,
+                             hipStream_t s);
+
+}  // namespace ppca

@@ -1,0 +1,676 @@
+// ppca_kernels.hip -- gfx950 (CDNA4) kernels of the PPCA EM hot path.
+//
+// pass_kernel<K, EM>: ONE streaming pass over the sample matrix X that fuses what
+// the reference does in five sweeps (reference = viodotcom/ppca_rs):
+//   infer            ppca/src/ppca_model.rs:221-227 (infer_one :195-208)
+//   cross moment     :281-293
+//   second moments   :294-306   (the reference's d sequential scans over N)
+//   noise 4-tuple    :328-358
+//   llk              :142-149
+// Persistent workgroups (one per CU) walk tiles of 32 samples:
+//   P1  coalesced row loads (prefetched one tile ahead in registers) ->
+//       x~ = observed ? x - mean : 0 into an LDS tile, mask words by wave ballot
+//   P2  [G | b] = [Mask | X~] (32 x 256) . [vech(c c^T) | C] (256 x (k'+k))
+//       on v_mfma_f64_16x16x4_f64 (true dense contractions over the 256 dims)
+//   P3  per-sample k x k SPD solve, one lane per sample, registers only:
+//       z, Sigma, ln det, quadratic form -> llk, noise terms, w P, w z
+//   P4  S/U/totals (256 x (k'+k+1)) += Mask^T . [wP | wz | w],
+//       cross/sumx (256 x (k+1))   += X~^T  . [wz | w]   on fp64 MFMA,
+//       accumulators persistent in registers across all tiles of the workgroup
+// and end with one deterministic per-workgroup partial that reduce_partials sums
+// in fixed order.  No atomics: results are bit-reproducible for a given grid.
+#include "ppca_internal.hpp"
+
+namespace ppca {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+template <int K>
+struct Cfg {
+    static constexpr int KP = K * (K + 1) / 2;
+    static constexpr int NTP = (KP + 15) / 16;  // column tiles holding vech(P)
+    static constexpr int NTM = NTP + 1;         // + the [w z | w] tile
+    static constexpr int B = FUSED_TILE;
+    static constexpr int DP = FUSED_MAX_D;
+    static constexpr int XS = DP + 2;           // x~ tile row stride (doubles): conflict-free A-operand reads
+    static constexpr int CS = K + 1;            // C tile row stride; column K is all zeros
+    static constexpr int GS = 16 * NTM + 1;     // [G | b] exchange row stride
+    static constexpr int WS = 16 * NTM + 2;     // [wP | wz | w] row stride
+    static constexpr int OFF_X = 0;
+    static constexpr int OFF_C = OFF_X + B * XS;
+    static constexpr int OFF_G = OFF_C + DP * CS;
+    static constexpr int OFF_W = OFF_G + 2 * B * GS;
+    static constexpr int OFF_M = OFF_W + B * WS;  // mask words, B x 4 u64
+    static constexpr int OFF_S = OFF_M + B * 4;   // xx[B] doubles, then m[B] ints
+    static constexpr int LDS_DOUBLES = OFF_S + 2 * B;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int K, bool EM>
+__global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
+    using cfg = Cfg<K>;
+    constexpr int KP = cfg::KP, NTP = cfg::NTP, NTM = cfg::NTM, B = cfg::B, XS = cfg::XS, CS = cfg::CS,
+                  GS = cfg::GS, WS = cfg::WS;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Xs = sm + cfg::OFF_X;
+    double *Cs = sm + cfg::OFF_C;
+    double *Gp = sm + cfg::OFF_G;
+    double *Ws = sm + cfg::OFF_W;
+    unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
+    double *xxs = sm + cfg::OFF_S;
+    int *mcnt = reinterpret_cast<int *>(sm + cfg::OFF_S + B);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bases stay in SGPRs
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int d = p.d;
+    const int64_t n = p.n;
+    const double *mC = p.model + MODEL_HDR;
+    const double *mMean = mC + (int64_t)d * K;
+    const double s2 = p.model[1], lnsig = p.model[2];
+
+    for (int idx = tid; idx < cfg::DP * CS; idx += FUSED_THREADS) {
+        int j = idx / CS, a = idx - j * CS;
+        Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
+    }
+    for (int idx = tid; idx < B * WS; idx += FUSED_THREADS) Ws[idx] = 0.0;
+
+    double mu[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int j = 64 * q + lane;
+        mu[q] = (j < d) ? mMean[j] : 0.0;
+    }
+    // (a, b) of packed column c = 16 t + (lane & 15); pad columns point at the zero column K
+    int pa[NTP], pb[NTP];
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) {
+        int c = 16 * t + l15;
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= c) ++a;
+        int b = c - a * (a + 1) / 2;
+        if (c >= KP) { a = K; b = K; }
+        pa[t] = a;
+        pb[t] = b;
+    }
+    const int colb = (l15 < K) ? l15 : K;
+
+    d4_t accM[4][NTM];
+    d4_t accX[4];
+    if constexpr (EM) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < NTM; ++t) accM[r][t] = d4_t{0, 0, 0, 0};
+            accX[r] = d4_t{0, 0, 0, 0};
+        }
+    }
+    double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;
+
+    const int64_t ntiles = (n + B - 1) / B;
+    double xr[8][4];
+    // Unconditional loads from clamped (always valid) addresses, one scalar base per row and
+    // one lane offset per quarter; out-of-range rows/dims are turned into NaN (= masked) after.
+    int jcl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) jcl[q] = (64 * q + lane < d) ? 64 * q + lane : d - 1;
+    auto load_tile = [&](int64_t tile) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t row = tile * B + wave * 8 + r;
+            const double *xrow = p.X + (row < n ? row : n - 1) * p.ldx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = xrow[jcl[q]];
+                xr[r][q] = (row < n && 64 * q + lane < d) ? v : __builtin_nan("");
+            }
+        }
+    };
+    if ((int64_t)blockIdx.x < ntiles) load_tile(blockIdx.x);
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ------------------------------------------------------------ P1
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int ri = wave * 8 + r;
+            double xx = 0.0;
+            int m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double v = xr[r][q];
+                bool fin = __builtin_isfinite(v);
+                double xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
+                unsigned long long bal = __ballot(fin);
+                if (lane == 0) Ms[ri * 4 + q] = bal;
+                Xs[ri * XS + 64 * q + lane] = xt;
+                xx += xt * xt;
+                m += __popcll(bal);
+            }
+            xx = wave_sum(xx);
+            if (lane == 0) {
+                xxs[ri] = xx;
+                mcnt[ri] = m;
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ P2
+        {
+            const int rt = wave & 1, kh = wave >> 1;
+            const int si = 16 * rt + l15;
+            const unsigned long long mw0 = Ms[si * 4 + 2 * kh], mw1 = Ms[si * 4 + 2 * kh + 1];
+            d4_t acc[NTM];
+#pragma unroll
+            for (int t = 0; t < NTM; ++t) acc[t] = d4_t{0, 0, 0, 0};
+            const double *xrow = Xs + si * XS + 128 * kh + l4;
+            const double *crow = Cs + (128 * kh + l4) * CS;
+#pragma unroll 8
+            for (int s = 0; s < 32; ++s) {
+                const double ax = xrow[4 * s];
+                const unsigned long long mw = (s < 16) ? mw0 : mw1;
+                const double am = ((mw >> (4 * (s & 15) + l4)) & 1ull) ? 1.0 : 0.0;
+                const double *cr = crow + 4 * s * CS;
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) acc[t] = mfma(am, cr[pa[t]] * cr[pb[t]], acc[t]);
+                acc[NTP] = mfma(ax, cr[colb], acc[NTP]);
+            }
+            double *g = Gp + kh * B * GS;
+#pragma unroll
+            for (int t = 0; t < NTM; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[(16 * rt + l4 + 4 * r) * GS + 16 * t + l15] = acc[t][r];
+        }
+        __syncthreads();
+        if constexpr (!EM) {
+            if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        }
+        // ------------------------------------------------------------ P3
+        if (tid < B) {
+            const int i = tid;
+            const int64_t row = tile * B + i;
+            const double *g0 = Gp + i * GS;
+            const double *g1 = g0 + B * GS;
+            const double xx = xxs[i];
+            const int m = mcnt[i];
+            const double wgt = (row < n) ? (p.w ? p.w[row] : 1.0) : 0.0;
+            double quad, zz, logdet, trminv;
+            double *wrow = Ws + i * WS;
+            auto gload = [&](int e) { return g0[e] + g1[e]; };
+            auto bload = [&](int a) { return g0[16 * NTP + a] + g1[16 * NTP + a]; };
+            if constexpr (EM) {
+                // W row = [w P (K') | 0.. | w z (K) | w | 0..]; z is parked unweighted in its slot
+                // until P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439) has been formed
+                double *zrow = wrow + 16 * NTP;
+                posterior_solve<K>(
+                    gload, bload, s2, [&](int a, double v) { zrow[a] = v; },
+                    [&](int a, int c, double v) { wrow[tri(a, c)] = wgt * (zrow[a] * zrow[c] + s2 * v); }, quad, zz,
+                    logdet, trminv);
+#pragma unroll
+                for (int a = 0; a < K; ++a) zrow[a] *= wgt;
+                zrow[K] = wgt;
+                if (m > 0) {  // :333 -- all-masked samples are filtered out of the noise sums
+                    sc_sq += wgt * (s2 * ((double)K - s2 * trminv));  // tr(C_o Sigma C_o^T) = <Sigma, G>  :345
+                    sc_dev += wgt * (xx - quad - s2 * zz);            // |x~ - C_o z|^2               :346
+                    sc_ne += (row < n) ? 1.0 : 0.0;
+                }
+            } else {
+                // post mode: W row = [z (K) | Sigma packed (K')] unweighted, for the output pass
+                posterior_solve<K>(
+                    gload, bload, s2, [&](int a, double v) { wrow[a] = v; },
+                    [&](int a, int c, double v) { wrow[K + tri(a, c)] = s2 * v; }, quad, zz, logdet, trminv);
+                if (row < n) {
+                    if (p.states) {
+#pragma unroll
+                        for (int a = 0; a < K; ++a) p.states[row * K + a] = wrow[a];
+                    }
+                    if (p.covs) {
+#pragma unroll
+                        for (int a = 0; a < K; ++a)
+#pragma unroll
+                            for (int c = 0; c <= a; ++c) {
+                                double v = wrow[K + tri(a, c)];
+                                p.covs[row * K * K + a * K + c] = v;
+                                p.covs[row * K * K + c * K + a] = v;
+                            }
+                    }
+                }
+            }
+            const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, K);
+            sc_llk += wgt * lk;
+            sc_w += wgt;
+            if constexpr (!EM) {
+                if (p.llks && row < n) p.llks[row] = lk;
+            }
+        }
+        __syncthreads();
+        if constexpr (EM) {
+            if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+            // -------------------------------------------------------- P4
+#pragma unroll 2
+            for (int s = 0; s < 8; ++s) {
+                const int smp = 4 * s + l4;
+                const unsigned long long mw = Ms[smp * 4 + wave];
+                double bw[NTM];
+#pragma unroll
+                for (int t = 0; t < NTM; ++t) bw[t] = Ws[smp * WS + 16 * t + l15];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double am = ((mw >> (16 * r + l15)) & 1ull) ? 1.0 : 0.0;
+                    const double ax = Xs[smp * XS + 64 * wave + 16 * r + l15];
+#pragma unroll
+                    for (int t = 0; t < NTM; ++t) accM[r][t] = mfma(am, bw[t], accM[r][t]);
+                    accX[r] = mfma(ax, bw[NTP], accX[r]);
+                }
+            }
+        } else if (p.recon) {
+            // output pass: smooth / extrapolate (ppca_model.rs:454-463) or covariance
+            // diagonals (:485-508, :542-577); one row per wave iteration, lanes over dims
+            for (int ri = wave; ri < B; ri += 4) {
+                const int64_t row = tile * B + ri;
+                if (row >= n) break;
+                const double *wrow = Ws + ri * WS;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = 64 * q + lane;
+                    if (j >= d) continue;
+                    const bool obs = (Ms[ri * 4 + q] >> lane) & 1ull;
+                    const double *cj = Cs + j * CS;
+                    double out;
+                    if (p.recon_mode <= 1) {
+                        double sm_ = mu[q];
+#pragma unroll
+                        for (int a = 0; a < K; ++a) sm_ += cj[a] * wrow[a];
+                        out = (p.recon_mode == 1 && obs) ? p.X[row * p.ldx + j] : sm_;
+                    } else {
+                        double v = 0.0;
+#pragma unroll
+                        for (int a = 0; a < K; ++a) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int c = 0; c < K; ++c) t += wrow[K + (a >= c ? tri(a, c) : tri(c, a))] * cj[c];
+                            v += cj[a] * t;
+                        }
+                        out = v + s2;
+                        if (p.recon_mode == 3 && obs) out = 0.0;
+                    }
+                    p.recon[row * (int64_t)d + j] = out;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------ epilogue
+    // scalars: deterministic reduction over the 32 solver lanes
+    if (wave == 0) {
+        double v0 = wave_sum(tid < B ? sc_sq : 0.0), v1 = wave_sum(tid < B ? sc_dev : 0.0),
+               v2 = wave_sum(tid < B ? sc_llk : 0.0), v3 = wave_sum(tid < B ? sc_w : 0.0),
+               v4 = wave_sum(tid < B ? sc_ne : 0.0);
+        if (lane == 0) {
+            double *sc;
+            if constexpr (EM) {
+                StatsLayout L(d, K);
+                sc = p.part + (int64_t)blockIdx.x * L.len + L.scalars;
+            } else {
+                sc = p.scal_part + (int64_t)blockIdx.x * 8;
+            }
+            sc[SC_SQERR] = v0;
+            sc[SC_DEVSQ] = v1;
+            sc[SC_LLK] = v2;
+            sc[SC_SUMW] = v3;
+            sc[SC_NONEMPTY] = v4;
+            sc[5] = 0.0;
+            sc[6] = 0.0;
+            sc[7] = 0.0;
+        }
+    }
+    if constexpr (EM) {
+        StatsLayout L(d, K);
+        double *out = p.part + (int64_t)blockIdx.x * L.len;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int dim = 64 * wave + 16 * r + l4 + 4 * q;  // C/D row of v_mfma_f64_16x16x4
+                if (dim >= d) continue;
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) {
+                    const int c = 16 * t + l15;
+                    if (c < KP) out[L.S + (int64_t)dim * KP + c] = accM[r][t][q];
+                }
+                if (l15 < K) {
+                    out[L.U + (int64_t)dim * K + l15] = accM[r][NTP][q];
+                    out[L.cross + (int64_t)dim * K + l15] = accX[r][q];
+                } else if (l15 == K) {
+                    out[L.totals + dim] = accM[r][NTP][q];
+                    out[L.sumx + dim] = accX[r][q];
+                }
+            }
+        }
+    }
+}
+
+// out[e] = sum over workgroup partials in fixed order (deterministic).
+__global__ void reduce_partials_kernel(const double *part, int grid_parts, int64_t len, double *out) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= len) return;
+    double s = 0.0;
+    for (int g = 0; g < grid_parts; ++g) s += part[(int64_t)g * len + e];
+    out[e] = s;
+}
+
+// M-step finalisation (ppca_model.rs:307-322, :360-377) -- one workgroup.
+template <int K>
+__global__ __launch_bounds__(256) void finalize_kernel(const double *stats, const double *min, double *mout, int d,
+                                                       double tau, int has_ig, double alpha, double beta) {
+    constexpr int KP = K * (K + 1) / 2;
+    StatsLayout L(d, K);
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double ts = 0.0;
+    for (int j = tid; j < d; j += 256) ts += stats[L.totals + j];
+    red[tid] = ts;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const double totsum = red[0];
+    const double sq = stats[L.scalars + SC_SQERR], dv = stats[L.scalars + SC_DEVSQ];
+    const double s2new = has_ig ? ((sq + dv) / 2.0 + beta) / (totsum / 2.0 + alpha + 1.0) : (sq + dv) / totsum;
+    const double *Cold = min + MODEL_HDR;
+    const double *Mold = Cold + (int64_t)d * K;
+    double *Cnew = mout + MODEL_HDR;
+    double *Mnew = Cnew + (int64_t)d * K;
+    for (int j = tid; j < d; j += 256) {
+        double S[KP], rhs[K], cn[K];
+#pragma unroll
+        for (int e = 0; e < KP; ++e) S[e] = stats[L.S + (int64_t)j * KP + e];
+        double cz = 0.0;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            rhs[a] = stats[L.cross + (int64_t)j * K + a];
+            cn[a] = Cold[(int64_t)j * K + a];  // keep the old row if the system is singular (:313-321)
+            cz += cn[a] * stats[L.U + (int64_t)j * K + a];
+        }
+        row_solve<K>(S, tau, rhs, cn);
+#pragma unroll
+        for (int a = 0; a < K; ++a) Cnew[(int64_t)j * K + a] = cn[a];
+        const double tot = stats[L.totals + j];
+        const double totdev = stats[L.sumx + j] - cz;  // sum_i w_i m_ij (x_ij - c_j.z_i - mu_j)  (:338-347)
+        Mnew[j] = (tot > 0.0 ? totdev / tot : 0.0) + Mold[j];  // :373-377
+    }
+    if (tid == 0) {
+        const double sig = sqrt(s2new);  // :389
+        mout[0] = sig;
+        mout[1] = sig * sig;
+        mout[2] = log(sig);
+        mout[3] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ synthetic data
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t rng_bits(uint64_t seed, uint64_t stream, uint64_t row, uint64_t col) {
+    return mix64(mix64(mix64(seed ^ (stream * 0xD1342543DE82EF95ull)) + row) + col * 0xA0761D6478BD642Full);
+}
+__device__ __forceinline__ double rng_u01(uint64_t bits) { return ((double)(bits >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+__device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t stream, uint64_t row, uint64_t col) {
+    double u1 = rng_u01(rng_bits(seed, stream, row, 2 * col));
+    double u2 = rng_u01(rng_bits(seed, stream, row, 2 * col + 1));
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+__global__ void synth_latent_kernel(double *z, int64_t row_offset, int64_t n_rows, int k, uint64_t seed) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * k) return;
+    int64_t i = idx / k;
+    int a = (int)(idx - i * k);
+    z[idx] = rng_normal(seed, 1, (uint64_t)(row_offset + i), (uint64_t)a);
+}
+
+__global__ void synth_data_kernel(const double *c, const double *mean, const double *z, double *x, int64_t row_offset,
+                                  int64_t n_rows, int d, int k, double sigma, double mask_prob, int mask_kind,
+                                  int mask_run, uint64_t seed) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * d) return;
+    int64_t i = idx / d;
+    int j = (int)(idx - i * d);
+    const uint64_t grow = (uint64_t)(row_offset + i);
+    double v = mean[j] + sigma * rng_normal(seed, 2, grow, (uint64_t)j);
+    for (int a = 0; a < k; ++a) v += c[(int64_t)j * k + a] * z[i * k + a];
+    bool masked;
+    if (mask_kind == 0) {
+        masked = rng_u01(rng_bits(seed, 3, grow, (uint64_t)j)) < mask_prob;
+    } else {
+        int start = (int)(rng_u01(rng_bits(seed, 4, grow, 0)) * d);
+        int off = j - start;
+        if (off < 0) off += d;
+        masked = off < mask_run;
+    }
+    x[idx] = masked ? __builtin_nan("") : v;
+}
+
+// present[j] = 1 if any sample has a finite value in dim j (Dataset::empty_dimensions, dataset.rs:194-222)
+__global__ void column_presence_kernel(const double *X, int64_t ldx, int64_t n, int d, int *present) {
+    int j = blockIdx.y * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    int64_t rows_per = (n + gridDim.x - 1) / gridDim.x;
+    int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = r0 + rows_per < n ? r0 + rows_per : n;
+    int any = 0;
+    for (int64_t r = r0; r < r1; ++r) any |= __builtin_isfinite(X[r * ldx + j]) ? 1 : 0;
+    if (any) atomicOr(&present[j], 1);
+}
+
+__global__ void fill_kernel(double *p, int64_t n, double v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void mfma_probe_kernel(const double *a, const double *b, double *out) {
+    const int lane = threadIdx.x;
+    d4_t acc = {0, 0, 0, 0};
+    // A[i][kk] at lane = i + 16 kk ; B[kk][j] at lane = j + 16 kk
+    acc = mfma(a[(lane & 15) * 4 + (lane >> 4)], b[(lane >> 4) * 16 + (lane & 15)], acc);
+    for (int r = 0; r < 4; ++r) out[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+}
+
+// ------------------------------------------------------------------ mixture helpers
+// mix.rs:283-295 (log-softmax of llk_c + log pi_c) and :304-309 (ln w_i + log posterior)
+__global__ void mix_posteriors_kernel(const double *llk, const double *logw, const double *w, int64_t n, int nm,
+                                      double *u, double *lse, double *logpost) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double mx = -INFINITY;
+    for (int c = 0; c < nm; ++c) mx = fmax(mx, llk[(int64_t)c * n + i] + logw[c]);
+    double s = 0.0;
+    for (int c = 0; c < nm; ++c) s += exp(llk[(int64_t)c * n + i] + logw[c] - mx);
+    const double ln = log(s);
+    if (lse) lse[i] = mx + ln;
+    const double wi = w ? w[i] : 1.0;
+    const double lw = wi > 0.0 ? log(wi) : -INFINITY;
+    for (int c = 0; c < nm; ++c) {
+        double lp = llk[(int64_t)c * n + i] + logw[c] - mx - ln;
+        if (logpost) logpost[i * nm + c] = lp;
+        if (u) u[(int64_t)c * n + i] = lw + lp;
+    }
+}
+
+template <bool MAX>
+__global__ void reduce_stage_kernel(const double *v, const double *w, int64_t n, double *out) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double acc = MAX ? -INFINITY : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+        double x = v[i];
+        if (MAX) {
+            if (x == x) acc = fmax(acc, x);  // NaNs are skipped (mix.rs:312-315)
+        } else {
+            acc += w ? x * w[i] : x;
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = MAX ? fmax(red[tid], red[tid + o]) : red[tid] + red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = red[0];
+}
+
+__global__ void exp_shift_kernel(const double *v, const double *mx, int64_t n, double *out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = exp(v[i] - *mx);
+}
+
+// ------------------------------------------------------------------ launchers
+int fused_grid(int64_t n, int n_cu) {
+    int64_t tiles = (n + FUSED_TILE - 1) / FUSED_TILE;
+    if (tiles < 1) tiles = 1;
+    return (int)(tiles < n_cu ? tiles : n_cu);
+}
+
+size_t fused_lds_bytes(int k) {
+    switch (k) {
+#define PPCA_CASE(KK) \
+    case KK:          \
+        return sizeof(double) * Cfg<KK>::LDS_DOUBLES;
+        PPCA_CASE(1) PPCA_CASE(2) PPCA_CASE(3) PPCA_CASE(4) PPCA_CASE(5) PPCA_CASE(6) PPCA_CASE(7) PPCA_CASE(8)
+        PPCA_CASE(9) PPCA_CASE(10)
+#undef PPCA_CASE
+    }
+    return 0;
+}
+
+template <int K, bool EM>
+static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
+    const size_t lds = sizeof(double) * Cfg<K>::LDS_DOUBLES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pass_kernel<K, EM>), dim3(grid), dim3(FUSED_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+#define PPCA_DISPATCH_K(k, EXPR)                         \
+    switch (k) {                                         \
+        case 1: { constexpr int KK = 1; EXPR; } break;   \
+        case 2: { constexpr int KK = 2; EXPR; } break;   \
+        case 3: { constexpr int KK = 3; EXPR; } break;   \
+        case 4: { constexpr int KK = 4; EXPR; } break;   \
+        case 5: { constexpr int KK = 5; EXPR; } break;   \
+        case 6: { constexpr int KK = 6; EXPR; } break;   \
+        case 7: { constexpr int KK = 7; EXPR; } break;   \
+        case 8: { constexpr int KK = 8; EXPR; } break;   \
+        case 9: { constexpr int KK = 9; EXPR; } break;   \
+        case 10: { constexpr int KK = 10; EXPR; } break; \
+        default: return hipErrorInvalidValue;            \
+    }
+
+hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
+    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true>(grid, a, s)));
+    return hipErrorInvalidValue;
+}
+hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s) {
+    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false>(grid, a, s)));
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s) {
+    int blocks = (int)((len + 255) / 256);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, part, grid_parts, len, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
+                           int has_ig, double alpha, double beta, hipStream_t s) {
+    PPCA_DISPATCH_K(k, hipLaunchKernelGGL((finalize_kernel<KK>), dim3(1), dim3(256), 0, s, stats, model_in, model_out,
+                                          d, tau, has_ig, alpha, beta));
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(const double *c_dev, const double *mean_dev, double *z_work, double *x_out, int64_t row_offset,
+                        int64_t n_rows, int d, int k, double sigma, double mask_prob, int mask_kind, int mask_run,
+                        uint64_t seed, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    int64_t nz = n_rows * k;
+    if (nz > 0)
+        hipLaunchKernelGGL(synth_latent_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, z_work, row_offset,
+                           n_rows, k, seed);
+    int64_t nx = n_rows * d;
+    hipLaunchKernelGGL(synth_data_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, c_dev, mean_dev, z_work,
+                       x_out, row_offset, n_rows, d, k, sigma, mask_prob, mask_kind, mask_run, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_column_presence(const double *X, int64_t ldx, int64_t n, int d, int *present, hipStream_t s) {
+    if (n <= 0 || d <= 0) return hipSuccess;
+    int gx = (int)((n + 4095) / 4096);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(column_presence_kernel, dim3(gx, (d + 255) / 256), dim3(256), 0, s, X, ldx, n, d, present);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(double *p, int64_t n, double v, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma_probe(const double *a16x4, const double *b4x16, double *out16x16, hipStream_t s) {
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, s, a16x4, b4x16, out16x16);
+    return hipGetLastError();
+}
+
+hipError_t launch_mix_posteriors(const double *llk, const double *logw_dev, const double *w, int64_t n, int nm,
+                                 double *u, double *lse, double *logpost, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mix_posteriors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, llk, logw_dev, w, n,
+                       nm, u, lse, logpost);
+    return hipGetLastError();
+}
+
+// two-stage deterministic reductions; work must hold >= 1024 doubles
+hipError_t launch_reduce_max(const double *v, int64_t n, double *out_scalar, double *work, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((reduce_stage_kernel<true>), dim3(blocks), dim3(256), 0, s, v, (const double *)nullptr, n, work);
+    hipLaunchKernelGGL((reduce_stage_kernel<true>), dim3(1), dim3(256), 0, s, work, (const double *)nullptr,
+                       (int64_t)blocks, out_scalar);
+    return hipGetLastError();
+}
+hipError_t launch_reduce_sum(const double *v, const double *w, int64_t n, double *out_scalar, double *work,
+                             hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((reduce_stage_kernel<false>), dim3(blocks), dim3(256), 0, s, v, w, n, work);
+    hipLaunchKernelGGL((reduce_stage_kernel<false>), dim3(1), dim3(256), 0, s, work, (const double *)nullptr,
+                       (int64_t)blocks, out_scalar);
+    return hipGetLastError();
+}
+hipError_t launch_exp_shift(const double *v, const double *max_dev, int64_t n, double *out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(exp_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, max_dev, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace ppca

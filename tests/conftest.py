@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import ppca_oracle
+
+    ppca_oracle.build()
+    return ppca_oracle
+
+
+@pytest.fixture(scope="session")
+def hiplib():
+    from ppca_rs_amd import build as b
+
+    b.build()
+    from ppca_rs_amd import _lib
+
+    return _lib.lib()

@@ -1,0 +1,260 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle and the
+committed golden vectors.  Tolerance: 1e-5 relative (BASELINE.json north_star, fp64);
+most checks are held far tighter because both sides are fp64."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+RTOL = 1e-5  # north_star tolerance
+
+
+@pytest.fixture(scope="module")
+def P(hiplib):
+    import ppca_rs_amd as p
+
+    return p
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_mfma_f64_lane_map(P):
+    """The C/D lane map the kernels assume for v_mfma_f64_16x16x4_f64 (asymmetric data)."""
+    from ppca_rs_amd import _lib
+
+    rng = np.random.default_rng(0)
+    a = rng.integers(-5, 6, (16, 4)).astype(np.float64)
+    b = rng.integers(-5, 6, (4, 16)).astype(np.float64)
+    out = np.zeros((16, 16))
+    ctx = _lib.default_context()
+    _lib.check(_lib.lib().ppca_debug_mfma_probe(ctx.handle, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out)))
+    np.testing.assert_array_equal(out, a @ b)
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_golden(P, path):
+    g = np.load(path)
+    x, s, c, mu = g["x"], float(g["s0"]), g["c0"], g["mu0"]
+    w = g["w"] if "w" in g else None
+    ds = P.Dataset(x, w)
+    m = P.PPCAModel(s, c, mu)
+    assert _rel(m.llks(ds), g["llks"]) < 1e-9
+    assert abs(m.llk(ds) - g["llk"]) < 1e-9 * abs(g["llk"])
+    inf = m.infer(ds)
+    assert _rel(inf.states(), g["states"]) < 1e-8
+    assert _rel(np.array(inf.covariances()), g["covs"]) < 1e-8
+    assert _rel(m.smooth(ds).numpy(), g["smooth"]) < 1e-9
+    ex = m.extrapolate(ds).numpy()
+    assert _rel(ex, g["extrapolate"]) < 1e-9
+    ob = np.isfinite(x)
+    np.testing.assert_array_equal(ex[ob], x[ob])  # observed values pass through bit-exactly
+    if "prior" in os.path.basename(path):
+        prior = (P.Prior().with_mean_prior(np.linspace(-1, 1, 8), 0.5 * np.eye(8) + 0.1)
+                 .with_isotropic_noise_prior(3.0, 2.0).with_transformation_precision(0.7))
+    else:
+        prior = None
+    for it in range(len(g["it_sigma"])):
+        m, llk = m.iterate_with_llk(ds, prior)
+        assert abs(llk - g["it_llk"][it]) < 1e-8 * abs(g["it_llk"][it])
+        assert abs(m.isotropic_noise - g["it_sigma"][it]) < RTOL * 1e-2 * g["it_sigma"][it]
+        assert _rel(m.transform, g["it_c"][it]) < RTOL * 1e-1
+        assert _rel(m.mean, g["it_mean"][it]) < RTOL * 1e-1
+    assert _rel(m.to_canonical().transform, g["canonical"]) < RTOL
+
+
+def test_stats_raw_against_oracle(P, oracle):
+    from ppca_rs_amd import _lib
+
+    x, _, _ = oracle.synth(1000, 256, 10, 0.3, 77)
+    x[10] = np.nan
+    rng = np.random.default_rng(5)
+    c, mu, s = rng.standard_normal((256, 10)), 0.1 * rng.standard_normal(256), 0.7
+    w = rng.uniform(0.5, 1.5, 1000)
+    ds, m = P.Dataset(x, w), P.PPCAModel(s, c, mu)
+    n = _lib.lib().ppca_stats_len(256, 10)
+    got = np.empty(n)
+    _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
+    want = oracle.stats(x, s, c, mu, w)
+    d, k, kp = 256, 10, 55
+    bounds = [0, d * k, d * k + d * kp, 2 * d * k + d * kp, 2 * d * k + d * kp + d, 2 * d * k + d * kp + 2 * d, n]
+    for name, a, b in zip(["cross", "S", "U", "sumx", "totals", "scalars"], bounds[:-1], bounds[1:]):
+        assert _rel(got[a:b], want[a:b]) < 1e-9, name
+
+
+@pytest.mark.parametrize("n,d,k,mp", [(10_000, 32, 4, 0.0), (20_000, 256, 10, 0.3), (3000, 200, 7, 0.5), (33, 5, 1, 0.2)])
+def test_em_iterations_match_oracle(P, oracle, n, d, k, mp):
+    """BASELINE configs 1/2 at oracle-sized N: 1 and several iterations from a fixed start."""
+    x, _, _ = oracle.synth(n, d, k, mp, 1000 + d)
+    rng = np.random.default_rng(2000 + d)
+    c, mu, s = rng.standard_normal((d, k)), np.zeros(d), 1.0
+    ds, m = P.Dataset(x), P.PPCAModel(s, c, mu)
+    iters = 10 if n <= 10_000 else 3
+    for it in range(iters):
+        want_llk = oracle.llk(x, s, c, mu)
+        s, c, mu = oracle.iterate(x, s, c, mu)
+        m, llk = m.iterate_with_llk(ds)
+        assert abs(llk - want_llk) < RTOL * 1e-3 * abs(want_llk), it
+        assert abs(m.isotropic_noise - s) < RTOL * s, it
+        assert _rel(m.transform, c) < RTOL, it
+        assert _rel(m.mean, mu) < RTOL, it
+    assert _rel(m.to_canonical().transform, oracle.to_canonical(c)) < RTOL
+    assert _rel(m.extrapolate(ds).numpy(), oracle.reconstruct(x, s, c, mu, "extrapolate")) < RTOL
+
+
+def test_edge_cases(P, oracle):
+    rng = np.random.default_rng(3)
+    d, k = 16, 3
+    c, mu, s = rng.standard_normal((d, k)), rng.standard_normal(d), 0.5
+    m = P.PPCAModel(s, c, mu)
+    # all samples fully masked -> llk 0, posterior N(0, I)
+    x = np.full((5, d), np.nan)
+    ds = P.Dataset(x)
+    assert m.llk(ds) == 0.0
+    inf = m.infer(ds)
+    np.testing.assert_array_equal(inf.states(), np.zeros((5, k)))
+    np.testing.assert_allclose(np.array(inf.covariances()), np.tile(np.eye(k), (5, 1, 1)), atol=1e-15)
+    np.testing.assert_allclose(m.smooth(ds).numpy(), np.tile(mu, (5, 1)))
+    assert ds.empty_dimensions() == list(range(d))
+    # +-inf is masked and comes back NaN (dataset.rs:19-22, :64-72)
+    x = rng.standard_normal((4, d))
+    x[0, 1], x[1, 2], x[2, 3] = np.inf, -np.inf, np.nan
+    ds = P.Dataset(x)
+    back = ds.numpy()
+    assert np.isnan(back[0, 1]) and np.isnan(back[1, 2]) and np.isnan(back[2, 3])
+    xn = np.where(np.isfinite(x), x, np.nan)
+    assert _rel(m.llks(ds), oracle.llks(xn, s, c, mu)) < 1e-10
+    # ragged: N not a multiple of the 32-sample tile, single row, strided / transposed views
+    for n in (1, 31, 32, 33, 65):
+        x = rng.standard_normal((n, d))
+        x[rng.random((n, d)) < 0.4] = np.nan
+        assert _rel(m.llks(P.Dataset(x)), oracle.llks(x, s, c, mu)) < 1e-10
+    big = rng.standard_normal((d, 40))
+    view = big.T[::2]  # non-contiguous (20, d)
+    assert _rel(P.Dataset(view).numpy(), np.ascontiguousarray(view)) == 0.0
+    # an empty dimension keeps its row and mean (ppca_model.rs:313-321, :373-377)
+    x = rng.standard_normal((200, d))
+    x[:, 7] = np.nan
+    ds = P.Dataset(x)
+    assert ds.empty_dimensions() == [7]
+    new = m.iterate(ds)
+    np.testing.assert_array_equal(new.transform[7], c[7])
+    assert new.mean[7] == mu[7]
+    s1, c1, m1 = oracle.iterate(x, s, c, mu)
+    assert _rel(new.transform, c1) < 1e-8 and abs(new.isotropic_noise - s1) < 1e-10
+    # shape mismatch and empty dataset raise
+    with pytest.raises(P.PPCAError):
+        m.llk(P.Dataset(np.zeros((3, d + 1))))
+    with pytest.raises(ValueError):
+        m.iterate(P.Dataset(np.zeros((0, d))))
+
+
+def test_dataset_ops(P):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((10, 4))
+    x[2, 1] = np.nan
+    w = np.arange(10, dtype=np.float64) + 1
+    ds = P.Dataset(x, w)
+    assert len(ds) == 10 and ds.output_size() == 4
+    np.testing.assert_array_equal(ds.weights(), w)
+    chunks = list(ds.chunks(3))  # stride ceil(10/3) = 4
+    assert [len(c) for c in chunks] == [4, 4, 2]
+    np.testing.assert_array_equal(chunks[1].weights(), w[4:8])
+    cat = P.Dataset.concat(chunks)
+    np.testing.assert_array_equal(np.nan_to_num(cat.numpy(), nan=-1), np.nan_to_num(x, nan=-1))
+    np.testing.assert_array_equal(cat.weights(), w)
+    re = ds.with_weights(np.ones(10))
+    np.testing.assert_array_equal(re.weights(), np.ones(10))
+    np.testing.assert_array_equal(np.isnan(re.numpy()), np.isnan(x))
+    ds2 = P.Dataset.load(ds.dump())
+    np.testing.assert_array_equal(ds2.weights(), w)
+
+
+def test_trainer_and_sampling(P, capsys):
+    """examples/toy_model.py flow: sample -> init -> train -> canonical, llk never decreases."""
+    real = P.PPCAModel(0.1, np.array([[1, 1], [0, 1], [0, 1]], dtype="float64"), np.array([[0], [1], [0]], dtype="float64"))
+    sample = real.sample(2000, 0.2, seed=7)
+    assert len(sample) == 2000
+    frac = np.isnan(sample.numpy()).mean()
+    assert 0.15 < frac < 0.25
+    np.testing.assert_array_equal(np.nan_to_num(sample.numpy()), np.nan_to_num(real.sample(2000, 0.2, seed=7).numpy()))
+    model = P.PPCATrainer(sample).train(state_size=2, n_iters=30, metric="llk", seed=3)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Masked PPCA iteration")]
+    assert len(lines) == 30 and lines[0].startswith("Masked PPCA iteration 1: llk=")
+    vals = [float(l.split("=")[1]) for l in lines]
+    assert all(b >= a - 1e-9 for a, b in zip(vals, vals[1:]))
+    assert model.isotropic_noise < 0.2
+    inf = model.infer(sample)
+    diag = inf.smoothed_covariances_diagonal(model).numpy()
+    assert diag.shape == (2000, 3) and (diag > 0).all()
+
+
+def test_mixture_against_oracle(P, oracle):
+    rng = np.random.default_rng(9)
+    d, k, nm, n = 24, 3, 3, 1500
+    parts = []
+    for c_ in range(nm):
+        xx, _, _ = oracle.synth(n // nm, d, k, 0.25, 300 + c_, mean_scale=3.0)
+        parts.append(xx)
+    x = np.concatenate(parts)
+    sig = np.array([1.0, 1.2, 0.9])
+    cs = rng.standard_normal((nm, d, k))
+    ms = rng.standard_normal((nm, d))
+    lw = np.log(np.array([0.3, 0.3, 0.4]))
+    ds = P.Dataset(x)
+    mix = P.PPCAMix([P.PPCAModel(sig[c_], cs[c_], ms[c_]) for c_ in range(nm)], lw)
+    assert _rel(mix.llks(ds), oracle.mix_llks(x, sig, cs, ms, lw)) < 1e-9
+    assert _rel(mix.infer_cluster(ds), oracle.mix_infer_cluster(x, sig, cs, ms, lw)) < 1e-8
+    for _ in range(3):
+        want = oracle.mix_iterate(x, sig, cs, ms, lw)
+        mix, llk = mix.iterate_with_llk(ds)
+        assert abs(llk - oracle.mix_llks(x, sig, cs, ms, lw).sum()) < 1e-8 * abs(llk)
+        sig, cs, ms, lw = want
+        for c_, mdl in enumerate(mix.models):
+            assert abs(mdl.isotropic_noise - sig[c_]) < RTOL * sig[c_]
+            assert _rel(mdl.transform, cs[c_]) < RTOL and _rel(mdl.mean, ms[c_]) < RTOL
+        assert _rel(mix.log_weights, lw) < RTOL
+
+
+def test_full_size_properties(P):
+    """BASELINE config 2 at full size (N = 1M, d = 256, k = 10, 30 % masked): size-independent
+    properties -- EM monotonicity, shard additivity of the statistics (the multi-GPU invariant),
+    run-to-run bit reproducibility, extrapolate keeps observed entries."""
+    from ppca_rs_amd import _lib
+
+    n, d, k = 1_000_000, 256, 10
+    rng = np.random.default_rng(12)
+    truth = P.PPCAModel(0.1, rng.standard_normal((d, k)), rng.standard_normal(d))
+    ds = truth.sample(n, 0.3, seed=1013)
+    m = P.PPCAModel.init(k, ds, seed=2011)
+    prev = -np.inf
+    for _ in range(4):
+        m, llk = m.iterate_with_llk(ds)
+        assert llk >= prev
+        prev = llk
+    L = _lib.lib().ppca_stats_len(d, k)
+    full = np.empty(L)
+    again = np.empty(L)
+    dev = m._device(ds._ctx)
+    _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, dev.h, _lib.ptr(full)))
+    _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, dev.h, _lib.ptr(again)))
+    np.testing.assert_array_equal(full, again)
+    acc = np.zeros(L)
+    for ch in ds.chunks(8):  # the 8-GPU sharding rule
+        part = np.empty(L)
+        _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ch._h, dev.h, _lib.ptr(part)))
+        acc += part
+    assert _rel(acc, full) < 1e-11
+    sub = ds._slice(0, 4096)
+    x = sub.numpy()
+    ex = m.extrapolate(sub).numpy()
+    ob = np.isfinite(x)
+    np.testing.assert_array_equal(ex[ob], x[ob])
+    assert np.isfinite(ex).all()

@@ -1,0 +1,147 @@
+"""Pins the CPU oracle: reference KATs, an independent dense-Gaussian evaluation,
+documented invariants, and the committed golden vectors (CPU only)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+C_TOY = np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]])  # ppca_model.rs:647-656
+
+
+def test_kat_quadratic_form(oracle):
+    # ppca_model.rs:658-665 asserts 34.219288 (a 6-digit literal); exact value 34.219269102989976
+    v = oracle.quadratic_form(0.1, C_TOY, [1.0, 1.0, 1.0])
+    assert abs(v - 34.219288) < 5e-5
+    assert abs(v - 34.219269102989976) < 1e-10
+
+
+def test_kat_covariance_log_det(oracle):
+    # ppca_model.rs:667-671 asserts -3.49328
+    v = oracle.covariance_log_det(0.1, C_TOY)
+    assert abs(v - (-3.49328)) < 5e-6
+    assert abs(v - (-3.4932797763741386)) < 1e-12
+
+
+def test_llk_toy_model_dense_gaussian(oracle):
+    # ppca_model.rs:673-680: inputs only upstream; expected from a dense N(mean, C C^T + s^2 I)
+    from scipy.stats import multivariate_normal as mvn
+
+    x = np.array([[1.0, 2.0, 3.0]])
+    mean = np.array([0.0, 1.0, 0.0])
+    want = mvn.logpdf(x[0], mean, C_TOY @ C_TOY.T + 0.01 * np.eye(3))
+    assert abs(oracle.llk(x, 0.1, C_TOY, mean) - want) < 1e-9
+    assert abs(want - (-152.9969524621925)) < 1e-8
+
+
+def _dense_check(oracle, x, s, c, mu):
+    from scipy.stats import multivariate_normal as mvn
+
+    l = oracle.llks(x, s, c, mu)
+    st, cv = oracle.infer(x, s, c, mu)
+    ex = oracle.reconstruct(x, s, c, mu, "extrapolate")
+    k = c.shape[1]
+    for i in range(len(x)):
+        ob = np.isfinite(x[i])
+        if ob.sum() == 0:
+            assert l[i] == 0.0 and np.all(st[i] == 0) and np.array_equal(cv[i], np.eye(k))
+            continue
+        co = c[ob]
+        cov = co @ co.T + s * s * np.eye(ob.sum())
+        assert abs(l[i] - mvn.logpdf(x[i, ob], mu[ob], cov)) < 1e-8 * max(1.0, abs(l[i]))
+        m = co.T @ co + s * s * np.eye(k)
+        z = np.linalg.solve(m, co.T @ (x[i, ob] - mu[ob]))
+        np.testing.assert_allclose(st[i], z, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(cv[i], s * s * np.linalg.inv(m), rtol=1e-7, atol=1e-10)
+        # conditional mean of the missing dims given the observed ones
+        if (~ob).any():
+            cm = mu[~ob] + c[~ob] @ co.T @ np.linalg.solve(cov, x[i, ob] - mu[ob])
+            np.testing.assert_allclose(ex[i, ~ob], cm, rtol=1e-7, atol=1e-9)
+        np.testing.assert_array_equal(ex[i, ob], x[i, ob])
+
+
+def test_dense_gaussian_agreement(oracle):
+    x, _, _ = oracle.synth(120, 10, 3, 0.35, 5)
+    x[7] = np.nan
+    rng = np.random.default_rng(3)
+    _dense_check(oracle, x, 0.6, rng.standard_normal((10, 3)), 0.2 * rng.standard_normal(10))
+
+
+def test_em_monotone_and_canonical_invariance(oracle):
+    # ppca_model.rs:263-265 (llk never decreases), :395-397 (canonical form keeps the llk)
+    x, _, _ = oracle.synth(400, 9, 2, 0.2, 9)
+    rng = np.random.default_rng(4)
+    s, c, mu = 1.0, rng.standard_normal((9, 2)), np.zeros(9)
+    prev = -np.inf
+    for _ in range(12):
+        l = oracle.llk(x, s, c, mu)
+        assert l >= prev - 1e-8 * abs(l)
+        prev = l
+        s, c, mu = oracle.iterate(x, s, c, mu)
+    cn = oracle.to_canonical(c)
+    assert abs(oracle.llk(x, s, cn, mu) - oracle.llk(x, s, c, mu)) < 1e-8 * abs(prev)
+    u, sv, _ = np.linalg.svd(c, full_matrices=False)
+    ref = u * sv
+    ref = ref * np.where(np.signbit(ref.sum(0)), -1.0, 1.0)
+    np.testing.assert_allclose(cn, ref, atol=1e-10)
+
+
+def test_stats_reproduce_iterate(oracle):
+    """The packed statistics (include/ppca_hip.h layout) carry everything iterate needs."""
+    x, _, _ = oracle.synth(150, 7, 3, 0.3, 13)
+    rng = np.random.default_rng(8)
+    s, c, mu = 0.9, rng.standard_normal((7, 3)), 0.1 * rng.standard_normal(7)
+    w = rng.uniform(0.2, 3.0, 150)
+    st = oracle.stats(x, s, c, mu, w)
+    d, k, kp = 7, 3, 6
+    cross = st[: d * k].reshape(d, k)
+    S = st[d * k: d * k + d * kp].reshape(d, kp)
+    U = st[d * k + d * kp: 2 * d * k + d * kp].reshape(d, k)
+    sumx = st[2 * d * k + d * kp: 2 * d * k + d * kp + d]
+    tot = st[2 * d * k + d * kp + d: 2 * d * k + d * kp + 2 * d]
+    sc = st[-8:]
+    s1, c1, m1 = oracle.iterate(x, s, c, mu, w)
+    tril = np.tril_indices(k)
+    for j in range(d):
+        sm = np.zeros((k, k))
+        sm[tril] = S[j]
+        sm = sm + sm.T - np.diag(np.diag(sm))
+        np.testing.assert_allclose(np.linalg.solve(sm, cross[j]), c1[j], rtol=1e-8)
+    np.testing.assert_allclose(np.sqrt((sc[0] + sc[1]) / tot.sum()), s1, rtol=1e-10)
+    np.testing.assert_allclose((sumx - (c * U).sum(1)) / tot + mu, m1, rtol=1e-9, atol=1e-12)
+    assert abs(sc[2] - oracle.llk(x, s, c, mu, w)) < 1e-9 * abs(sc[2])
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_golden_vectors(oracle, path):
+    g = np.load(path)
+    x, s, c, mu = g["x"], float(g["s0"]), g["c0"], g["mu0"]
+    w = g["w"] if "w" in g else None
+    np.testing.assert_allclose(oracle.llks(x, s, c, mu), g["llks"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(oracle.llk(x, s, c, mu, w), g["llk"], rtol=1e-12)
+    st, cv = oracle.infer(x, s, c, mu)
+    np.testing.assert_allclose(st, g["states"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(cv, g["covs"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(oracle.reconstruct(x, s, c, mu, "extrapolate"), g["extrapolate"], rtol=1e-10, atol=1e-12)
+
+
+def test_mixture_oracle_consistency(oracle):
+    x, _, _ = oracle.synth(200, 6, 2, 0.2, 17)
+    rng = np.random.default_rng(5)
+    nm = 3
+    sig = np.array([0.7, 1.1, 0.9])
+    cs = rng.standard_normal((nm, 6, 2))
+    ms = rng.standard_normal((nm, 6))
+    lw = np.log(np.array([0.2, 0.5, 0.3]))
+    lp = oracle.mix_infer_cluster(x, sig, cs, ms, lw)
+    np.testing.assert_allclose(np.exp(lp).sum(1), 1.0, rtol=1e-12)
+    l = oracle.mix_llks(x, sig, cs, ms, lw)
+    comp = np.stack([oracle.llks(x, sig[c], cs[c], ms[c]) + lw[c] for c in range(nm)], 1)
+    np.testing.assert_allclose(l, np.log(np.exp(comp - comp.max(1, keepdims=True)).sum(1)) + comp.max(1), rtol=1e-12)
+    prev = l.sum()
+    for _ in range(5):  # mix.rs:267-270: llk never decreases
+        sig, cs, ms, lw = oracle.mix_iterate(x, sig, cs, ms, lw)
+        cur = oracle.mix_llks(x, sig, cs, ms, lw).sum()
+        assert cur >= prev - 1e-8 * abs(cur)
+        prev = cur
