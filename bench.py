@@ -72,7 +72,7 @@ def main() -> None:
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mask", type=float, default=0.3)
-    ap.add_argument("--cpu-rows", type=int, default=20_000)
+    ap.add_argument("--cpu-rows", type=int, default=100_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
