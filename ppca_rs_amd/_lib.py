@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libppca_hip.so")
+LIB_PATH = os.environ.get("PPCA_HIP_LIB", os.path.join(_HERE, "libppca_hip.so"))  # override: diagnostic builds
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

@@ -33,15 +33,17 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: str = LIB) -> str:
+    """extra_flags / lib_path: diagnostic builds (e.g. -DPPCA_PHASE_TIMING into another .so)."""
+    if not force and not extra_flags and not needs_build():
         return LIB
     hipcc = _hipcc()
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC, src.replace(".hip", ".diag.o" if extra_flags else ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra_flags, "-c", os.path.join(CSRC, src),
+               "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((subprocess.Popen(cmd), cmd))
@@ -49,12 +51,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--timing" in sys.argv:
+        print(build(force=True, verbose=True, extra_flags=("-DPPCA_PHASE_TIMING",),
+                    lib_path=os.path.join(HERE, "libppca_hip_timing.so")))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -530,6 +530,11 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
     a.d = ds->d;
     a.model = model->p();
     a.part = static_cast<double *>(ctx->part->p);
+#ifdef PPCA_PHASE_TIMING
+    BufRef dbg;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 8, &dbg)) return rc;
+    a.dbg = static_cast<double *>(dbg->p);
+#endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
         HIP_TRY(hipEventCreate(&e0));
@@ -542,6 +547,20 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
         ctx->events.emplace_back(e0, e1);
     }
     HIP_TRY(launch_reduce_partials(a.part, grid, L.len, stats_dev, ctx->stream));
+#ifdef PPCA_PHASE_TIMING
+    {
+        std::vector<double> h((size_t)grid * 8);
+        HIP_TRY(hipMemcpyAsync(h.data(), a.dbg, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < grid; ++g)
+            for (int i = 0; i < 8; ++i) t[i] += h[(size_t)g * 8 + i] / grid;
+        const double tiles = (double)((ds->n + FUSED_TILE - 1) / FUSED_TILE) / grid;
+        fprintf(stderr, "[ppca phase cycles/tile] P1 %.0f (stage %.0f reduce %.0f tail+barrier %.0f)  P2 %.0f  P3 %.0f  P4 %.0f  (tiles/WG %.1f)\n",
+                (t[0] + t[4] + t[5]) / tiles, t[4] / tiles, t[5] / tiles, t[0] / tiles, t[1] / tiles, t[2] / tiles,
+                t[3] / tiles, tiles);
+    }
+#endif
     return PPCA_OK;
 }
 

@@ -36,6 +36,7 @@ struct PassArgs {
     double *covs;         // n x k x k
     double *recon;        // n x d
     int recon_mode;       // 0 smooth, 1 extrapolate, 2 smoothed cov diag, 3 extrapolated cov diag
+    double *dbg;          // diagnostic builds (-DPPCA_PHASE_TIMING): [grid][4] phase cycle sums
 };
 
 // Number of workgroups the fused pass wants for n rows on a device with n_cu CUs.

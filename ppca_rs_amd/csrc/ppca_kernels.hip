@@ -119,49 +119,81 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
     const int64_t ntiles = (n + B - 1) / B;
     double xr[8][4];
     // Unconditional loads from clamped (always valid) addresses, one scalar base per row and
-    // one lane offset per quarter; out-of-range rows/dims are turned into NaN (= masked) after.
+    // one lane offset per quarter: nothing between issue and first use, so the loads of a whole
+    // tile stay in flight behind P4.  Out-of-range rows/dims are masked when consumed in P1.
     int jcl[4];
+    bool dim_ok[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) jcl[q] = (64 * q + lane < d) ? 64 * q + lane : d - 1;
+    for (int q = 0; q < 4; ++q) {
+        dim_ok[q] = 64 * q + lane < d;
+        jcl[q] = dim_ok[q] ? 64 * q + lane : d - 1;
+    }
     auto load_tile = [&](int64_t tile) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int64_t row = tile * B + wave * 8 + r;
             const double *xrow = p.X + (row < n ? row : n - 1) * p.ldx;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double v = xrow[jcl[q]];
-                xr[r][q] = (row < n && 64 * q + lane < d) ? v : __builtin_nan("");
-            }
+            for (int q = 0; q < 4; ++q) xr[r][q] = xrow[jcl[q]];  // validity is applied when consumed (P1)
         }
     };
-    if ((int64_t)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    load_tile(blockIdx.x);
 
+#ifdef PPCA_PHASE_TIMING
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#define PPCA_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define PPCA_STAMP(i)
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ------------------------------------------------------------ P1
+        {
+            // Wave-uniform results (mask words, popcounts, row sums) are gathered into the lane that
+            // will store them -- lane 4r+q keeps mask word q of row r, lane r keeps xx_r / m_r -- so
+            // the whole wave does ONE compact store per array instead of 48 single-address stores.
+            double xxr[8];
+            unsigned long long myw = 0ull;
+            int mym = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int ri = wave * 8 + r;
-            double xx = 0.0;
-            int m = 0;
+            for (int r = 0; r < 8; ++r) {
+                const int ri = wave * 8 + r;
+                const bool row_ok = tile * B + ri < n;
+                double xx = 0.0;
+                int m = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double v = xr[r][q];
-                bool fin = __builtin_isfinite(v);
-                double xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
-                unsigned long long bal = __ballot(fin);
-                if (lane == 0) Ms[ri * 4 + q] = bal;
-                Xs[ri * XS + 64 * q + lane] = xt;
-                xx += xt * xt;
-                m += __popcll(bal);
+                for (int q = 0; q < 4; ++q) {
+                    const double v = xr[r][q];
+                    const bool fin = row_ok && dim_ok[q] && __builtin_isfinite(v);
+                    const double xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
+                    const unsigned long long bal = __ballot(fin);
+                    myw = (lane == 4 * r + q) ? bal : myw;
+                    Xs[ri * XS + 64 * q + lane] = xt;
+                    xx += xt * xt;
+                    m += __popcll(bal);
+                }
+                xxr[r] = xx;
+                mym = (lane == r) ? m : mym;
             }
-            xx = wave_sum(xx);
-            if (lane == 0) {
-                xxs[ri] = xx;
-                mcnt[ri] = m;
+            PPCA_STAMP(4)
+            // eight independent butterfly reductions, interleaved step by step for ILP
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) xxr[r] += __shfl_xor(xxr[r], o, 64);
+            }
+            double myxx = 0.0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) myxx = (lane == r) ? xxr[r] : myxx;
+            PPCA_STAMP(5)
+            if (lane < 32) Ms[wave * 32 + lane] = myw;
+            if (lane < 8) {
+                xxs[wave * 8 + lane] = myxx;
+                mcnt[wave * 8 + lane] = mym;
             }
         }
         __syncthreads();
+        PPCA_STAMP(0)
         // ------------------------------------------------------------ P2
         {
             const int rt = wave & 1, kh = wave >> 1;
@@ -170,17 +202,26 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
             d4_t acc[NTM];
 #pragma unroll
             for (int t = 0; t < NTM; ++t) acc[t] = d4_t{0, 0, 0, 0};
+            // lane-constant base pointers; after full unrolling every LDS read below is
+            // base + immediate offset (no per-step address arithmetic)
             const double *xrow = Xs + si * XS + 128 * kh + l4;
             const double *crow = Cs + (128 * kh + l4) * CS;
-#pragma unroll 8
+            const double *cpa[NTP], *cpb[NTP];
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) {
+                cpa[t] = crow + pa[t];
+                cpb[t] = crow + pb[t];
+            }
+            const double *cpc = crow + colb;
+            const int sh = l4;
+#pragma unroll
             for (int s = 0; s < 32; ++s) {
                 const double ax = xrow[4 * s];
                 const unsigned long long mw = (s < 16) ? mw0 : mw1;
-                const double am = ((mw >> (4 * (s & 15) + l4)) & 1ull) ? 1.0 : 0.0;
-                const double *cr = crow + 4 * s * CS;
+                const double am = ((mw >> (4 * (s & 15) + sh)) & 1ull) ? 1.0 : 0.0;
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) acc[t] = mfma(am, cr[pa[t]] * cr[pb[t]], acc[t]);
-                acc[NTP] = mfma(ax, cr[colb], acc[NTP]);
+                for (int t = 0; t < NTP; ++t) acc[t] = mfma(am, cpa[t][4 * s * CS] * cpb[t][4 * s * CS], acc[t]);
+                acc[NTP] = mfma(ax, cpc[4 * s * CS], acc[NTP]);
             }
             double *g = Gp + kh * B * GS;
 #pragma unroll
@@ -189,9 +230,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
                 for (int r = 0; r < 4; ++r) g[(16 * rt + l4 + 4 * r) * GS + 16 * t + l15] = acc[t][r];
         }
         __syncthreads();
-        if constexpr (!EM) {
-            if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
-        }
+        PPCA_STAMP(1)
+        if constexpr (!EM) load_tile(tile + gridDim.x);  // unconditional: rows are clamped, see load_tile
         // ------------------------------------------------------------ P3
         if (tid < B) {
             const int i = tid;
@@ -251,8 +291,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
             }
         }
         __syncthreads();
+        PPCA_STAMP(2)
         if constexpr (EM) {
-            if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+            load_tile(tile + gridDim.x);  // unconditional (clamped rows): no old value stays live across P2/P3
             // -------------------------------------------------------- P4
 #pragma unroll 2
             for (int s = 0; s < 8; ++s) {
@@ -306,7 +347,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
             }
         }
         __syncthreads();
+        PPCA_STAMP(3)
     }
+#ifdef PPCA_PHASE_TIMING
+    if (p.dbg && tid == 0)
+        for (int i = 0; i < 8; ++i) p.dbg[(int64_t)blockIdx.x * 8 + i] = (double)tph[i];
+#endif
 
     // ------------------------------------------------------------ epilogue
     // scalars: deterministic reduction over the 32 solver lanes
