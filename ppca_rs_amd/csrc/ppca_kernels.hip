@@ -346,6 +346,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
                 }
             }
         }
+#ifdef PPCA_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: charge the prefetch wait to P4
+#endif
         __syncthreads();
         PPCA_STAMP(3)
     }
