@@ -25,6 +25,9 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HBM bytes per sample of the dominant kernel from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE,
+# gfx950 correction calibrated on a known byte count): profiles/r01/README.md
+PMC_BYTES_PER_SAMPLE = 2085.6
 FP64_PEAK_TFLOPS = 78.6  # fp64 vector = fp64 matrix spec
 
 
@@ -171,7 +174,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": PMC_BYTES_PER_SAMPLE * rows_local if (d, k) == (256, 10) else None,
+                "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01/README.md)",
                 "kernel": "ppca::pass_kernel<10, true>",
                 "kernel_avg_ms": kern_avg_ms,
                 "kernel_launches": launches,
