@@ -19,6 +19,8 @@
 //       accumulators persistent in registers across all tiles of the workgroup
 // and end with one deterministic per-workgroup partial that reduce_partials sums
 // in fixed order.  No atomics: results are bit-reproducible for a given grid.
+#include <cstdlib>
+
 #include "ppca_internal.hpp"
 
 namespace ppca {
@@ -55,11 +57,22 @@ __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-template <int K, bool EM>
-__global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
+// NW = waves per workgroup: 4 (one wave per SIMD, 512 registers each) or 8 (two waves per SIMD,
+// 256 registers each, every wave owning half as many accumulator tiles).
+template <int K, bool EM, int NW>
+__global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     using cfg = Cfg<K>;
     constexpr int KP = cfg::KP, NTP = cfg::NTP, NTM = cfg::NTM, B = cfg::B, XS = cfg::XS, CS = cfg::CS,
                   GS = cfg::GS, WS = cfg::WS;
+    constexpr int THREADS = 64 * NW;
+    constexpr int RPW = B / NW;          // rows staged per wave in P1
+    constexpr int KS = NW / 2;           // K-splits of the [G | b] contraction (x 2 row tiles = NW waves)
+    constexpr int DPS = cfg::DP / KS;    // dims per split
+    constexpr int STEPS = DPS / 4;       // MFMA k-steps per split
+    constexpr int WPS = DPS / 64;        // mask words per split
+    constexpr int RT = 16 / NW;          // accumulator row tiles (16 dims each) per wave in P4
+    constexpr int DW = cfg::DP / NW;     // dims owned by a wave in P4
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Xs = sm + cfg::OFF_X;
     double *Cs = sm + cfg::OFF_C;
@@ -78,11 +91,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
     const double *mMean = mC + (int64_t)d * K;
     const double s2 = p.model[1], lnsig = p.model[2];
 
-    for (int idx = tid; idx < cfg::DP * CS; idx += FUSED_THREADS) {
+    for (int idx = tid; idx < cfg::DP * CS; idx += THREADS) {
         int j = idx / CS, a = idx - j * CS;
         Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
     }
-    for (int idx = tid; idx < B * WS; idx += FUSED_THREADS) Ws[idx] = 0.0;
+    for (int idx = tid; idx < B * WS; idx += THREADS) Ws[idx] = 0.0;
 
     double mu[4];
 #pragma unroll
@@ -104,11 +117,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
     }
     const int colb = (l15 < K) ? l15 : K;
 
-    d4_t accM[4][NTM];
-    d4_t accX[4];
+    d4_t accM[RT][NTM];
+    d4_t accX[RT];
     if constexpr (EM) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RT; ++r) {
 #pragma unroll
             for (int t = 0; t < NTM; ++t) accM[r][t] = d4_t{0, 0, 0, 0};
             accX[r] = d4_t{0, 0, 0, 0};
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
     double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;
 
     const int64_t ntiles = (n + B - 1) / B;
-    double xr[8][4];
+    double xr[RPW][4];
     // Unconditional loads from clamped (always valid) addresses, one scalar base per row and
     // one lane offset per quarter: nothing between issue and first use, so the loads of a whole
     // tile stay in flight behind P4.  Out-of-range rows/dims are masked when consumed in P1.
@@ -130,8 +143,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
     }
     auto load_tile = [&](int64_t tile) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int64_t row = tile * B + wave * 8 + r;
+        for (int r = 0; r < RPW; ++r) {
+            const int64_t row = tile * B + wave * RPW + r;
             const double *xrow = p.X + (row < n ? row : n - 1) * p.ldx;
 #pragma unroll
             for (int q = 0; q < 4; ++q) xr[r][q] = xrow[jcl[q]];  // validity is applied when consumed (P1)
@@ -151,20 +164,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
         {
             // Wave-uniform results (mask words, popcounts, row sums) are gathered into the lane that
             // will store them -- lane 4r+q keeps mask word q of row r, lane r keeps xx_r / m_r -- so
-            // the whole wave does ONE compact store per array instead of 48 single-address stores.
-            double xxr[8];
+            // the whole wave does ONE compact store per array instead of many single-address stores.
+            double xxr[RPW];
             unsigned long long myw = 0ull;
             int mym = 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int ri = wave * 8 + r;
+            for (int r = 0; r < RPW; ++r) {
+                const int ri = wave * RPW + r;
                 const bool row_ok = tile * B + ri < n;
                 double xx = 0.0;
                 int m = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double v = xr[r][q];
-                    const bool fin = row_ok && dim_ok[q] && __builtin_isfinite(v);
+                    const bool fin = (int)row_ok & (int)dim_ok[q] & (int)__builtin_isfinite(v);
                     const double xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
                     const unsigned long long bal = __ballot(fin);
                     myw = (lane == 4 * r + q) ? bal : myw;
@@ -176,36 +189,38 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
                 mym = (lane == r) ? m : mym;
             }
             PPCA_STAMP(4)
-            // eight independent butterfly reductions, interleaved step by step for ILP
+            // independent butterfly reductions, interleaved step by step for ILP
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) xxr[r] += __shfl_xor(xxr[r], o, 64);
+                for (int r = 0; r < RPW; ++r) xxr[r] += __shfl_xor(xxr[r], o, 64);
             }
             double myxx = 0.0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) myxx = (lane == r) ? xxr[r] : myxx;
+            for (int r = 0; r < RPW; ++r) myxx = (lane == r) ? xxr[r] : myxx;
             PPCA_STAMP(5)
-            if (lane < 32) Ms[wave * 32 + lane] = myw;
-            if (lane < 8) {
-                xxs[wave * 8 + lane] = myxx;
-                mcnt[wave * 8 + lane] = mym;
+            if (lane < 4 * RPW) Ms[wave * 4 * RPW + lane] = myw;
+            if (lane < RPW) {
+                xxs[wave * RPW + lane] = myxx;
+                mcnt[wave * RPW + lane] = mym;
             }
         }
         __syncthreads();
         PPCA_STAMP(0)
         // ------------------------------------------------------------ P2
         {
-            const int rt = wave & 1, kh = wave >> 1;
+            const int rt = wave & 1, kq = wave >> 1;
             const int si = 16 * rt + l15;
-            const unsigned long long mw0 = Ms[si * 4 + 2 * kh], mw1 = Ms[si * 4 + 2 * kh + 1];
+            unsigned long long mw[WPS];
+#pragma unroll
+            for (int i = 0; i < WPS; ++i) mw[i] = Ms[si * 4 + WPS * kq + i];
             d4_t acc[NTM];
 #pragma unroll
             for (int t = 0; t < NTM; ++t) acc[t] = d4_t{0, 0, 0, 0};
             // lane-constant base pointers; after full unrolling every LDS read below is
             // base + immediate offset (no per-step address arithmetic)
-            const double *xrow = Xs + si * XS + 128 * kh + l4;
-            const double *crow = Cs + (128 * kh + l4) * CS;
+            const double *xrow = Xs + si * XS + DPS * kq + l4;
+            const double *crow = Cs + (DPS * kq + l4) * CS;
             const double *cpa[NTP], *cpb[NTP];
 #pragma unroll
             for (int t = 0; t < NTP; ++t) {
@@ -213,81 +228,101 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
                 cpb[t] = crow + pb[t];
             }
             const double *cpc = crow + colb;
-            const int sh = l4;
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
+            for (int s = 0; s < STEPS; ++s) {
                 const double ax = xrow[4 * s];
-                const unsigned long long mw = (s < 16) ? mw0 : mw1;
-                const double am = ((mw >> (4 * (s & 15) + sh)) & 1ull) ? 1.0 : 0.0;
+                const double am = ((mw[s / 16] >> (4 * (s & 15) + l4)) & 1ull) ? 1.0 : 0.0;
 #pragma unroll
                 for (int t = 0; t < NTP; ++t) acc[t] = mfma(am, cpa[t][4 * s * CS] * cpb[t][4 * s * CS], acc[t]);
                 acc[NTP] = mfma(ax, cpc[4 * s * CS], acc[NTP]);
             }
-            double *g = Gp + kh * B * GS;
+            // K-split partials -> two buffers, summed in a fixed order (deterministic):
+            // G = (p0 [+ p2]) + (p1 [+ p3]); the bracketed terms are added in place by their owner
+            double *g = Gp + (kq & 1) * B * GS;
+            if (kq < 2) {
 #pragma unroll
-            for (int t = 0; t < NTM; ++t)
+                for (int t = 0; t < NTM; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[(16 * rt + l4 + 4 * r) * GS + 16 * t + l15] = acc[t][r];
+                    for (int r = 0; r < 4; ++r) g[(16 * rt + l4 + 4 * r) * GS + 16 * t + l15] = acc[t][r];
+            }
+            if constexpr (KS == 4) {
+                __syncthreads();
+                if (kq >= 2) {
+#pragma unroll
+                    for (int t = 0; t < NTM; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g[(16 * rt + l4 + 4 * r) * GS + 16 * t + l15] += acc[t][r];
+                }
+            }
         }
         __syncthreads();
         PPCA_STAMP(1)
         if constexpr (!EM) load_tile(tile + gridDim.x);  // unconditional: rows are clamped, see load_tile
         // ------------------------------------------------------------ P3
-        if (tid < B) {
-            const int i = tid;
+        // Every wave factors every sample (lane = sample, redundantly, in parallel) and the waves
+        // share the independent columns of M^-1; wave 0 also owns z, llk and the scalars.
+        if (lane < B) {
+            const int i = lane;
             const int64_t row = tile * B + i;
             const double *g0 = Gp + i * GS;
             const double *g1 = g0 + B * GS;
-            const double xx = xxs[i];
-            const int m = mcnt[i];
             const double wgt = (row < n) ? (p.w ? p.w[row] : 1.0) : 0.0;
-            double quad, zz, logdet, trminv;
+            const int m = mcnt[i];
             double *wrow = Ws + i * WS;
-            auto gload = [&](int e) { return g0[e] + g1[e]; };
-            auto bload = [&](int a) { return g0[16 * NTP + a] + g1[16 * NTP + a]; };
-            if constexpr (EM) {
-                // W row = [w P (K') | 0.. | w z (K) | w | 0..]; z is parked unweighted in its slot
-                // until P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439) has been formed
-                double *zrow = wrow + 16 * NTP;
-                posterior_solve<K>(
-                    gload, bload, s2, [&](int a, double v) { zrow[a] = v; },
-                    [&](int a, int c, double v) { wrow[tri(a, c)] = wgt * (zrow[a] * zrow[c] + s2 * v); }, quad, zz,
-                    logdet, trminv);
+            Posterior<K> post;
+            const double logdet = post.factor([&](int e) { return g0[e] + g1[e]; }, s2);
+            double z[K], quad, zz;
+            post.solve([&](int a) { return g0[16 * NTP + a] + g1[16 * NTP + a]; }, z, quad, zz);
+            double trpart = 0.0;
 #pragma unroll
-                for (int a = 0; a < K; ++a) zrow[a] *= wgt;
-                zrow[K] = wgt;
-                if (m > 0) {  // :333 -- all-masked samples are filtered out of the noise sums
-                    sc_sq += wgt * (s2 * ((double)K - s2 * trminv));  // tr(C_o Sigma C_o^T) = <Sigma, G>  :345
-                    sc_dev += wgt * (xx - quad - s2 * zz);            // |x~ - C_o z|^2               :346
-                    sc_ne += (row < n) ? 1.0 : 0.0;
-                }
-            } else {
-                // post mode: W row = [z (K) | Sigma packed (K')] unweighted, for the output pass
-                posterior_solve<K>(
-                    gload, bload, s2, [&](int a, double v) { wrow[a] = v; },
-                    [&](int a, int c, double v) { wrow[K + tri(a, c)] = s2 * v; }, quad, zz, logdet, trminv);
-                if (row < n) {
-                    if (p.states) {
-#pragma unroll
-                        for (int a = 0; a < K; ++a) p.states[row * K + a] = wrow[a];
-                    }
-                    if (p.covs) {
-#pragma unroll
-                        for (int a = 0; a < K; ++a)
-#pragma unroll
-                            for (int c = 0; c <= a; ++c) {
-                                double v = wrow[K + tri(a, c)];
-                                p.covs[row * K * K + a * K + c] = v;
-                                p.covs[row * K * K + c * K + a] = v;
-                            }
-                    }
+            for (int c = 0; c < K; ++c) {
+                if (column_owner(K, c, NW) != wave) continue;
+                if constexpr (EM) {
+                    // P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439), weighted
+                    trpart += post.minv_column(
+                        c, [&](int a, int cc, double v) { wrow[tri(a, cc)] = wgt * (z[a] * z[cc] + s2 * v); });
+                } else {
+                    trpart += post.minv_column(c, [&](int a, int cc, double v) {
+                        const double sv = s2 * v;
+                        wrow[K + tri(a, cc)] = sv;  // post mode: W row = [z (K) | Sigma packed (K')]
+                        if (p.covs && row < n) {
+                            p.covs[row * K * K + a * K + cc] = sv;
+                            p.covs[row * K * K + cc * K + a] = sv;
+                        }
+                    });
                 }
             }
-            const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, K);
-            sc_llk += wgt * lk;
-            sc_w += wgt;
-            if constexpr (!EM) {
-                if (p.llks && row < n) p.llks[row] = lk;
+            if constexpr (EM) {
+                // tr(C_o Sigma C_o^T) = <Sigma, G> = s2 (K - s2 tr M^-1)  (:345); each wave carries the
+                // share of its columns.  All-masked samples are filtered out of the noise sums (:333).
+                if (m > 0) sc_sq -= wgt * s2 * s2 * trpart;
+            }
+            if (wave == 0) {
+                const double xx = xxs[i];
+                if constexpr (EM) {
+                    double *zrow = wrow + 16 * NTP;  // W row = [w P (K') | 0.. | w z (K) | w | 0..]
+#pragma unroll
+                    for (int a = 0; a < K; ++a) zrow[a] = wgt * z[a];
+                    zrow[K] = wgt;
+                    if (m > 0) {
+                        sc_sq += wgt * s2 * (double)K;
+                        sc_dev += wgt * (xx - quad - s2 * zz);  // |x~ - C_o z|^2  (:346)
+                        sc_ne += (row < n) ? 1.0 : 0.0;
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < K; ++a) wrow[a] = z[a];
+                    if (p.states && row < n) {
+#pragma unroll
+                        for (int a = 0; a < K; ++a) p.states[row * K + a] = z[a];
+                    }
+                }
+                const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, K);
+                sc_llk += wgt * lk;
+                sc_w += wgt;
+                if constexpr (!EM) {
+                    if (p.llks && row < n) p.llks[row] = lk;
+                }
             }
         }
         __syncthreads();
@@ -295,17 +330,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
         if constexpr (EM) {
             load_tile(tile + gridDim.x);  // unconditional (clamped rows): no old value stays live across P2/P3
             // -------------------------------------------------------- P4
-#pragma unroll 2
+            constexpr int UNR = (NW == 4) ? 2 : 4;
+#pragma unroll UNR
             for (int s = 0; s < 8; ++s) {
                 const int smp = 4 * s + l4;
-                const unsigned long long mw = Ms[smp * 4 + wave];
+                const unsigned long long mw = Ms[smp * 4 + (DW * wave) / 64];
                 double bw[NTM];
 #pragma unroll
                 for (int t = 0; t < NTM; ++t) bw[t] = Ws[smp * WS + 16 * t + l15];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double am = ((mw >> (16 * r + l15)) & 1ull) ? 1.0 : 0.0;
-                    const double ax = Xs[smp * XS + 64 * wave + 16 * r + l15];
+                for (int r = 0; r < RT; ++r) {
+                    const double am = ((mw >> (((DW * wave) & 63) + 16 * r + l15)) & 1ull) ? 1.0 : 0.0;
+                    const double ax = Xs[smp * XS + DW * wave + 16 * r + l15];
 #pragma unroll
                     for (int t = 0; t < NTM; ++t) accM[r][t] = mfma(am, bw[t], accM[r][t]);
                     accX[r] = mfma(ax, bw[NTP], accX[r]);
@@ -314,7 +350,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
         } else if (p.recon) {
             // output pass: smooth / extrapolate (ppca_model.rs:454-463) or covariance
             // diagonals (:485-508, :542-577); one row per wave iteration, lanes over dims
-            for (int ri = wave; ri < B; ri += 4) {
+            for (int ri = wave; ri < B; ri += NW) {
                 const int64_t row = tile * B + ri;
                 if (row >= n) break;
                 const double *wrow = Ws + ri * WS;
@@ -346,9 +382,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
                 }
             }
         }
-#ifdef PPCA_PHASE_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: charge the prefetch wait to P4
-#endif
         __syncthreads();
         PPCA_STAMP(3)
     }
@@ -358,11 +391,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
 #endif
 
     // ------------------------------------------------------------ epilogue
-    // scalars: deterministic reduction over the 32 solver lanes
+    // scalars: deterministic reduction over the 32 solver lanes of each wave, then over the waves
+    {
+        const double sq_w = wave_sum(lane < B ? sc_sq : 0.0);
+        if (lane == 0) xxs[wave] = sq_w;  // xxs is free after the last tile
+    }
+    __syncthreads();
     if (wave == 0) {
-        double v0 = wave_sum(tid < B ? sc_sq : 0.0), v1 = wave_sum(tid < B ? sc_dev : 0.0),
-               v2 = wave_sum(tid < B ? sc_llk : 0.0), v3 = wave_sum(tid < B ? sc_w : 0.0),
-               v4 = wave_sum(tid < B ? sc_ne : 0.0);
+        double v0 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v0 += xxs[w];
+        double v1 = wave_sum(lane < B ? sc_dev : 0.0), v2 = wave_sum(lane < B ? sc_llk : 0.0),
+               v3 = wave_sum(lane < B ? sc_w : 0.0), v4 = wave_sum(lane < B ? sc_ne : 0.0);
         if (lane == 0) {
             double *sc;
             if constexpr (EM) {
@@ -385,10 +425,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void pass_kernel(PassArgs p) {
         StatsLayout L(d, K);
         double *out = p.part + (int64_t)blockIdx.x * L.len;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RT; ++r) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int dim = 64 * wave + 16 * r + l4 + 4 * q;  // C/D row of v_mfma_f64_16x16x4
+                const int dim = DW * wave + 16 * r + l4 + 4 * q;  // C/D row of v_mfma_f64_16x16x4
                 if (dim >= d) continue;
 #pragma unroll
                 for (int t = 0; t < NTP; ++t) {
@@ -604,18 +644,30 @@ size_t fused_lds_bytes(int k) {
     return 0;
 }
 
-template <int K, bool EM>
+template <int K, bool EM, int NW>
 static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
     const size_t lds = sizeof(double) * Cfg<K>::LDS_DOUBLES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((pass_kernel<K, EM>), dim3(grid), dim3(FUSED_THREADS), lds, s, a);
+    hipLaunchKernelGGL((pass_kernel<K, EM, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
+}
+
+// Waves per workgroup of the EM pass: 4 (one per SIMD, 512 registers each).  PPCA_FUSED_WAVES=8
+// selects the two-waves-per-SIMD variant, measured slower in round 1 (25.5 vs 38.4 EM it/s at
+// N = 10M: the per-sample solve spills at 256 registers and the MFMA phases do not speed up).
+static int em_waves() {
+    static int nw = 0;
+    if (nw == 0) {
+        const char *e = getenv("PPCA_FUSED_WAVES");
+        nw = (e && atoi(e) == 8) ? 8 : 4;
+    }
+    return nw;
 }
 
 #define PPCA_DISPATCH_K(k, EXPR)                         \
@@ -634,11 +686,15 @@ static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
     }
 
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
-    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true>(grid, a, s)));
+    if (em_waves() == 4) {
+        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4>(grid, a, s)));
+    } else {
+        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 8>(grid, a, s)));
+    }
     return hipErrorInvalidValue;
 }
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s) {
-    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false>(grid, a, s)));
+    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4>(grid, a, s)));
     return hipErrorInvalidValue;
 }
 

@@ -48,7 +48,7 @@ enum { SC_SQERR = 0, SC_DEVSQ = 1, SC_LLK = 2, SC_SUMW = 3, SC_NONEMPTY = 4 };
 // Scheduling fence (device only): keeps hipcc from hoisting a whole phase's LDS
 // operand loads to its top, which would double the live registers of the solve.
 PPCA_HD void sched_fence() {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PPCA_SOLVE_FENCES)
+#if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
@@ -62,93 +62,104 @@ PPCA_HD double fast_rsqrt(double s) {
 }
 
 // ---------------------------------------------------------------------------
-// Posterior of one sample, compile-time K.  Only the packed Cholesky factor
-// (K' doubles) is live in registers; everything else streams through callbacks
-// so that the caller decides where operands and results live (LDS rows):
-//   gload(e)        -> packed Gram entry e of G = C_o^T C_o
-//   bload(a)        -> entry a of b = C_o^T x~
-//   zstore(a, v)    <- z_a, z = M^-1 b with M = G + s2 I
-//   mstore(a, c, v) <- (M^-1)_{ac}, a >= c       (Sigma = s2 M^-1)
-// and returns quad = b^T M^-1 b, zz = |z|^2, logdet = ln det M, trminv = tr M^-1.
-// Phases: left-looking Cholesky (diagonal slots keep 1/L_aa, the only form ever
-// used), forward/backward substitution, in-place inverse of the triangular factor,
-// M^-1 = L^-T L^-1 entry by entry.
-template <int K, class GLoad, class BLoad, class ZStore, class MStore>
-PPCA_HD void posterior_solve(GLoad gload, BLoad bload, double s2, ZStore zstore, MStore mstore, double &quad,
-                             double &zz, double &logdet, double &trminv) {
-    constexpr int KP = K * (K + 1) / 2;
+// Posterior of one sample, compile-time K, packed Cholesky factor in registers.
+//   factor(gload, s2)    M = G + s2 I = L L^T, gload(e) -> packed Gram entry e; returns ln det M
+//                        (diagonal slots keep 1/L_aa, the only form ever used)
+//   solve(bload, z, ..)  z = M^-1 b, quad = b^T M^-1 b, zz = |z|^2
+//   minv_column(c, st)   column c of M^-1 (rows a >= c) by two triangular solves, st(a, c, v);
+//                        returns (M^-1)_cc.  Columns are independent, so the waves of a
+//                        workgroup share them (column_owner) after factoring redundantly.
+template <int K>
+struct Posterior {
+    static constexpr int KP = K * (K + 1) / 2;
     double L[KP];
-    double mant = 1.0;
-    int ex = 0;
+
+    template <class GLoad>
+    PPCA_HD double factor(GLoad gload, double s2) {
+        double mant = 1.0;
+        int ex = 0;
 #pragma unroll
-    for (int a = 0; a < K; ++a) {
+        for (int a = 0; a < K; ++a) {
 #pragma unroll
-        for (int c = 0; c <= a; ++c) {
-            double s = gload(tri(a, c));
-            if (c == a) s += s2;
+            for (int c = 0; c <= a; ++c) {
+                double s = gload(tri(a, c));
+                if (c == a) s += s2;
 #pragma unroll
-            for (int t = 0; t < c; ++t) s -= L[tri(a, t)] * L[tri(c, t)];
-            if (c < a) {
-                L[tri(a, c)] = s * L[tri(c, c)];
-            } else {
-                L[tri(a, a)] = fast_rsqrt(s);  // 1 / L_aa
-                int e;
-                mant *= frexp(s, &e);  // ln det M = ln prod(pivots), overflow-safe
-                ex += e;
+                for (int t = 0; t < c; ++t) s -= L[tri(a, t)] * L[tri(c, t)];
+                if (c < a) {
+                    L[tri(a, c)] = s * L[tri(c, c)];
+                } else {
+                    L[tri(a, a)] = fast_rsqrt(s);  // 1 / L_aa
+                    int e;
+                    mant *= frexp(s, &e);  // ln det M = ln prod(pivots), overflow-safe
+                    ex += e;
+                }
             }
+            sched_fence();  // keep the Gram loads of later rows from being hoisted (register pressure)
         }
-        sched_fence();
+        return log(mant) + (double)ex * LN_2;
     }
-    logdet = log(mant) + (double)ex * LN_2;
-    {
-        double y[K];
+
+    template <class BLoad>
+    PPCA_HD void solve(BLoad bload, double (&z)[K], double &quad, double &zz) const {
         quad = 0.0;
 #pragma unroll
         for (int a = 0; a < K; ++a) {
             double s = bload(a);
 #pragma unroll
-            for (int t = 0; t < a; ++t) s -= L[tri(a, t)] * y[t];
-            y[a] = s * L[tri(a, a)];
-            quad += y[a] * y[a];
+            for (int t = 0; t < a; ++t) s -= L[tri(a, t)] * z[t];
+            z[a] = s * L[tri(a, a)];  // y = L^-1 b
+            quad += z[a] * z[a];
         }
         zz = 0.0;
 #pragma unroll
         for (int a = K - 1; a >= 0; --a) {
-            double s = y[a];
+            double s = z[a];
 #pragma unroll
-            for (int t = a + 1; t < K; ++t) s -= L[tri(t, a)] * y[t];
-            y[a] = s * L[tri(a, a)];  // z_a overwrites y_a
-            zz += y[a] * y[a];
-            zstore(a, y[a]);
+            for (int t = a + 1; t < K; ++t) s -= L[tri(t, a)] * z[t];
+            z[a] = s * L[tri(a, a)];  // z = L^-T y
+            zz += z[a] * z[a];
         }
         sched_fence();
     }
-    // in-place inverse of the lower-triangular factor (columns right to left, rows
-    // bottom to top, so every original entry is read before it is overwritten)
+
+    template <class Store>
+    PPCA_HD double minv_column(int c, Store st) const {
+        double u[K];
 #pragma unroll
-    for (int j = K - 2; j >= 0; --j) {
+        for (int a = 0; a < K; ++a) {
+            if (a < c) continue;
+            double s = (a == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int a = K - 1; a > j; --a) {
-            double s = 0.0;
+            for (int t = 0; t < a; ++t)
+                if (t >= c) s -= L[tri(a, t)] * u[t];
+            u[a] = s * L[tri(a, a)];
+        }
 #pragma unroll
-            for (int t = j + 1; t <= a; ++t) s += L[tri(a, t)] * L[tri(t, j)];
-            L[tri(a, j)] = -s * L[tri(j, j)];
+        for (int a = K - 1; a >= 0; --a) {
+            if (a < c) continue;
+            double s = u[a];
+#pragma unroll
+            for (int t = a + 1; t < K; ++t) s -= L[tri(t, a)] * u[t];
+            u[a] = s * L[tri(a, a)];  // x_a overwrites u_a (only u_t, t > a, already final, are read)
+            st(a, c, u[a]);
         }
         sched_fence();
+        return u[c];
     }
-    trminv = 0.0;
-#pragma unroll
-    for (int a = 0; a < K; ++a) {
-#pragma unroll
-        for (int c = 0; c <= a; ++c) {
-            double s = 0.0;
-#pragma unroll
-            for (int t = a; t < K; ++t) s += L[tri(t, a)] * L[tri(t, c)];
-            if (c == a) trminv += s;
-            mstore(a, c, s);
-        }
-        sched_fence();
+};
+
+// Which of nw workers owns column c of M^-1: greedy balance of the (K - c)^2 solve costs.
+PPCA_HD constexpr int column_owner(int K, int c, int nw) {
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int own = 0;
+    for (int cc = 0; cc <= c; ++cc) {
+        own = 0;
+        for (int w = 1; w < nw; ++w)
+            if (load[w] < load[own]) own = w;
+        load[own] += (K - cc) * (K - cc);
     }
+    return own;
 }
 
 // Per-sample log-likelihood from the solve's by-products (ppca_model.rs:124-139):
