@@ -76,6 +76,8 @@ struct ppca_ctx {
     BufRef scal;  // post-pass scalars: [grid][8] partials + 8 reduced
     size_t scal_cap = 0;
     BufRef work;  // 2048 doubles for reductions
+    BufRef gws;   // workspace of the generic split pipeline
+    size_t gws_cap = 0;
 };
 
 struct ppca_dataset {
@@ -115,6 +117,7 @@ extern "C" int32_t ppca_abi_version(void) { return PPCA_ABI_VERSION; }
 extern "C" int32_t ppca_path_kind(int32_t d, int32_t k) {
     if (d < 1 || k < 1) return PPCA_ERR_INVALID;
     if (d <= FUSED_MAX_D && k <= FUSED_MAX_K) return 1;
+    if (k <= GENERIC_MAX_K) return 0;
     return PPCA_ERR_UNSUPPORTED;
 }
 
@@ -122,8 +125,8 @@ static int check_path(int d, int k) {
     int kind = ppca_path_kind(d, k);
     if (kind == PPCA_ERR_INVALID) return fail(PPCA_ERR_INVALID, "invalid shape d=%d k=%d", d, k);
     if (kind < 0)
-        return fail(PPCA_ERR_UNSUPPORTED, "shape d=%d k=%d is outside the fused kernel (d <= %d, k <= %d)", d, k,
-                    FUSED_MAX_D, FUSED_MAX_K);
+        return fail(PPCA_ERR_UNSUPPORTED, "state size %d is not supported (d=%d): the kernels cover k <= %d", k, d,
+                    GENERIC_MAX_K);
     return PPCA_OK;
 }
 
@@ -520,6 +523,12 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
         HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * (size_t)L.len, ctx->stream));
         return PPCA_OK;
     }
+    if (ppca_path_kind(model->d, model->k) == 0) {
+        if (int rc = ensure(ctx->gws, ctx->gws_cap, generic_workspace_bytes(model->d, model->k, ds->n))) return rc;
+        HIP_TRY(generic_em_accumulate(ds->X, ds->d, ds->w, ds->n, ds->d, model->k, model->p(), stats_dev, ctx->gws->p,
+                                      ctx->n_cu, ctx->stream));
+        return PPCA_OK;
+    }
     const int grid = fused_grid(ds->n, ctx->n_cu);
     if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)grid * L.len)) return rc;
     PassArgs a{};
@@ -679,9 +688,15 @@ extern "C" int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const
     const int d = model_in->d, k = model_in->k;
     const double tau = prior ? prior->transformation_precision : 0.0;
     const int has_ig = prior ? prior->has_isotropic_noise_prior : 0;
-    HIP_TRY(launch_finalize(k, d, stats_dev, model_in->p(), out->p(), tau, has_ig,
-                            has_ig ? prior->isotropic_noise_alpha : 0.0, has_ig ? prior->isotropic_noise_beta : 0.0,
-                            ctx->stream));
+    if (ppca_path_kind(d, k) == 0) {
+        HIP_TRY(generic_finalize(k, d, stats_dev, model_in->p(), out->p(), tau, has_ig,
+                                 has_ig ? prior->isotropic_noise_alpha : 0.0, has_ig ? prior->isotropic_noise_beta : 0.0,
+                                 ctx->n_cu, ctx->stream));
+    } else {
+        HIP_TRY(launch_finalize(k, d, stats_dev, model_in->p(), out->p(), tau, has_ig,
+                                has_ig ? prior->isotropic_noise_alpha : 0.0, has_ig ? prior->isotropic_noise_beta : 0.0,
+                                ctx->stream));
+    }
     if (prior && prior->has_mean_prior) {
         // rare branch (d x d solve, prior.rs:97-110): host round trip
         const StatsLayout L(d, k);
@@ -734,6 +749,15 @@ extern "C" int ppca_stats_raw(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
 static int run_post(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *llks_dev, double *states_dev,
                     double *covs_dev, double *recon_dev, int recon_mode, double **scal_out) {
     if (int rc = use_device(ctx)) return rc;
+    if (ppca_path_kind(model->d, model->k) == 0) {
+        if (int rc = ensure(ctx->scal, ctx->scal_cap, sizeof(double) * 16)) return rc;
+        if (int rc = ensure(ctx->gws, ctx->gws_cap, generic_workspace_bytes(model->d, model->k, ds->n))) return rc;
+        double *scal8 = static_cast<double *>(ctx->scal->p);
+        HIP_TRY(generic_post(ds->X, ds->d, ds->w, ds->n, ds->d, model->k, model->p(), scal8, llks_dev, states_dev,
+                             covs_dev, recon_dev, recon_mode, ctx->gws->p, ctx->n_cu, ctx->stream));
+        if (scal_out) *scal_out = scal8;
+        return PPCA_OK;
+    }
     const int grid = fused_grid(ds->n, ctx->n_cu);
     if (int rc = ensure(ctx->scal, ctx->scal_cap, sizeof(double) * ((size_t)grid * 8 + 8))) return rc;
     double *scal = static_cast<double *>(ctx->scal->p);

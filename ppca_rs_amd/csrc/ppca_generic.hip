@@ -1,0 +1,586 @@
+// ppca_generic.hip -- split pipeline for shapes the fused kernel does not cover
+// (d > 256 or k > 10, up to k = 64; BASELINE config 4: d = 1024, k = 64).
+//
+// Same mathematics as pass_kernel (ppca_kernels.hip) and the same reference items
+// (ppca/src/ppca_model.rs:195-208 infer_one, :281-358 M-step sweeps, :142-149 llk), but
+// the k x k per-sample state no longer fits registers and the d x k(k+1)/2 statistics no
+// longer fit one workgroup, so the pass is cut into dense contractions over sample chunks:
+//   Q        = vech(c_j c_j^T)                      (d x k')            qtab_kernel
+//   G | b    = Mask . Q  |  X~ . C                  (chunk x (k'+k))    gemm_kernel  (fp64 MFMA)
+//   solve    : per sample, one wave: Cholesky in LDS, z, M^-1 -> w P, w z, llk   solve_kernel
+//   S, U, totals += Mask^T . [wP | wz | w]          (d x (k'+k+1))      gemm_kernel
+//   cross, sumx  += X~^T  . [wz | w]                (d x (k+1))         gemm_kernel
+// Chunk results are accumulated in chunk order (deterministic).  Correctness first: the
+// GEMM is a plain LDS-staged 64x64 tile kernel on v_mfma_f64_16x16x4_f64.
+#include <algorithm>
+#include <cstdlib>
+
+#include "ppca_internal.hpp"
+
+namespace ppca {
+
+typedef double d4g_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double gwave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ Q table
+__global__ void qtab_kernel(const double *model, int d, int k, double *q) {
+    const int kp = k * (k + 1) / 2;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)d * kp) return;
+    int j = (int)(idx / kp), e = (int)(idx - (int64_t)j * kp);
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= e) ++a;
+    int b = e - a * (a + 1) / 2;
+    const double *c = model + MODEL_HDR + (int64_t)j * k;
+    q[idx] = c[a] * c[b];
+}
+
+// ------------------------------------------------------------------ row statistics
+// xx_i = sum_obs (x - mu)^2, m_i = #observed; one wave per row.
+__global__ void rowstats_kernel(const double *X, int64_t ldx, int64_t n, int d, const double *model, int k, double *xx,
+                                double *mcount) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double *mean = model + MODEL_HDR + (int64_t)d * k;
+    double s = 0.0, m = 0.0;
+    for (int j = lane; j < d; j += 64) {
+        double v = X[row * ldx + j];
+        if (__builtin_isfinite(v)) {
+            double t = v - mean[j];
+            s += t * t;
+            m += 1.0;
+        }
+    }
+    s = gwave_sum(s);
+    m = gwave_sum(m);
+    if (lane == 0) {
+        xx[row] = s;
+        mcount[row] = m;
+    }
+}
+
+// ------------------------------------------------------------------ GEMM
+// C[M x N] (+)= A[M x K] . B[K x N], A generated from the sample matrix:
+//   AMODE 0: A[i][j] = mask(X[i][j])            (M = samples, K = dims)
+//   AMODE 1: A[i][j] = x~_ij                    (M = samples, K = dims)
+//   AMODE 2: A[j][i] = mask(X[i][j])            (M = dims,    K = samples)
+//   AMODE 3: A[j][i] = x~_ij                    (M = dims,    K = samples)
+// B is dense row-major (ldb).  Output element (r, c): c < ncols0 -> out0[r*ld0 + c],
+// else out1[r*ld1 + (c - ncols0)].
+struct GemmArgs {
+    const double *X;
+    int64_t ldx;
+    const double *mean;
+    const double *B;
+    int64_t ldb;
+    int64_t M, N, K;
+    double *out0;
+    int64_t ld0;
+    int64_t ncols0;
+    double *out1;
+    int64_t ld1;
+    int accumulate;
+};
+
+template <int AMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ double As[64][17];
+    __shared__ double Bs[16][65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+    d4g_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = d4g_t{0, 0, 0, 0};
+    for (int64_t k0 = 0; k0 < g.K; k0 += 16) {
+        // A tile: 64 (M) x 16 (K)
+        if (AMODE < 2) {
+            const int i = tid >> 2, kk = (tid & 3) * 4;
+            const int64_t row = m0 + i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t col = k0 + kk + u;
+                double v = 0.0;
+                if (row < g.M && col < g.K) {
+                    double x = g.X[row * g.ldx + col];
+                    bool fin = __builtin_isfinite(x);
+                    v = (AMODE == 0) ? (fin ? 1.0 : 0.0) : (fin ? x - g.mean[col] : 0.0);
+                }
+                As[i][kk + u] = v;
+            }
+        } else {
+            const int i = tid >> 4, jj = (tid & 15) * 4;  // sample i of the K-chunk, 4 dims
+            const int64_t srow = k0 + i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t dim = m0 + jj + u;
+                double v = 0.0;
+                if (srow < g.K && dim < g.M) {
+                    double x = g.X[srow * g.ldx + dim];
+                    bool fin = __builtin_isfinite(x);
+                    v = (AMODE == 2) ? (fin ? 1.0 : 0.0) : (fin ? x - g.mean[dim] : 0.0);
+                }
+                As[jj + u][i] = v;
+            }
+        }
+        // B tile: 16 (K) x 64 (N)
+        {
+            const int kk = tid >> 4, cc = (tid & 15) * 4;
+            const int64_t kr = k0 + kk;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t col = n0 + cc + u;
+                Bs[kk][cc + u] = (kr < g.K && col < g.N) ? g.B[kr * g.ldb + col] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double a = As[16 * wave + l15][4 * s + l4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[4 * s + l4][16 * t + l15], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = m0 + 16 * wave + l4 + 4 * r, col = n0 + 16 * t + l15;
+            if (row < g.M && col < g.N) {
+                double *dst = (col < g.ncols0) ? g.out0 + row * g.ld0 + col : g.out1 + row * g.ld1 + (col - g.ncols0);
+                *dst = g.accumulate ? *dst + acc[t][r] : acc[t][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------ wave-level SPD tools (runtime k <= 64)
+// Matrix in LDS, row-major with leading dimension LD; lane r owns row r.  The factor overwrites
+// the lower triangle, diagonal slots hold 1/L_pp.  Returns false when a pivot is not positive.
+__device__ bool wave_cholesky(volatile double *Mw, int k, int LD, int lane, double &logdet) {
+    bool ok = true;
+    double mant = 1.0;
+    int ex = 0;
+    for (int p = 0; p < k; ++p) {
+        const double piv = Mw[p * LD + p];
+        ok = ok && (piv > 0.0) && (piv < 1.0e308);
+        const double rinv = 1.0 / sqrt(piv);
+        int e;
+        mant *= frexp(piv, &e);
+        ex += e;
+        double lrp = 0.0;
+        if (lane > p && lane < k) {
+            lrp = Mw[lane * LD + p] * rinv;
+            Mw[lane * LD + p] = lrp;
+        }
+        if (lane == p) Mw[p * LD + p] = rinv;
+        for (int c = p + 1; c < k; ++c) {
+            const double lcp = Mw[c * LD + p];
+            if (lane >= c && lane < k) Mw[lane * LD + c] -= lrp * lcp;
+        }
+    }
+    logdet = log(mant) + (double)ex * LN_2;
+    return ok;
+}
+
+// Solve (L L^T) z = v, lane r holds v_r on entry and z_r on exit; quad = |L^-1 v|^2.
+__device__ double wave_chol_solve(volatile double *Mw, int k, int LD, int lane, double v, double &quad) {
+    for (int p = 0; p < k; ++p) {
+        const double yp = __shfl(v, p, 64) * Mw[p * LD + p];
+        if (lane == p) v = yp;
+        if (lane > p && lane < k) v -= Mw[lane * LD + p] * yp;
+    }
+    quad = gwave_sum(lane < k ? v * v : 0.0);
+    for (int p = k - 1; p >= 0; --p) {
+        const double zp = __shfl(v, p, 64) * Mw[p * LD + p];
+        if (lane == p) v = zp;
+        if (lane < p) v -= Mw[p * LD + lane] * zp;
+    }
+    return v;
+}
+
+// Uw[a][c] = (M^-1)_{ac}; lane c owns column c (two triangular solves per column, lanes independent).
+__device__ void wave_chol_inverse(volatile double *Mw, volatile double *Uw, int k, int LD, int lane) {
+    const int c = lane < k ? lane : k - 1;
+    for (int a = 0; a < k; ++a) {
+        double s = (a == c) ? 1.0 : 0.0;
+        for (int t = 0; t < a; ++t) s -= Mw[a * LD + t] * Uw[t * LD + c];
+        if (lane < k) Uw[a * LD + c] = (a >= c) ? s * Mw[a * LD + a] : 0.0;
+    }
+    for (int a = k - 1; a >= 0; --a) {
+        double s = Uw[a * LD + c];
+        for (int t = a + 1; t < k; ++t) s -= Mw[t * LD + a] * Uw[t * LD + c];
+        if (lane < k) Uw[a * LD + c] = s * Mw[a * LD + a];
+    }
+}
+
+// ------------------------------------------------------------------ per-sample solve
+struct SolveArgs {
+    double *G;        // [n][kp] in: packed Gram; out (EM): w P packed
+    double *Bz;       // [n][k+1] in: b (k); out (EM): [w z | w]
+    const double *xx; // [n]
+    const double *mc; // [n]
+    const double *w;  // [n] or nullptr
+    int64_t n;
+    int k;
+    const double *model;  // device model buffer: sigma^2 and ln sigma are read on the device
+    double *sc;       // [n][4]: sq, dev, w*llk, nonempty  (EM: sq/dev filled; post: only llk)
+    int em;
+    double *llks;     // post (nullable): per-sample llk
+    double *states;   // post (nullable): [n][k]
+    double *covs;     // post (nullable): [n][k][k]
+};
+
+__global__ __launch_bounds__(128) void solve_kernel(SolveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = a.k, kp = k * (k + 1) / 2, LD = k | 1;
+    volatile double *Mw = gsm + (size_t)wave * (2 * k * LD + 64);
+    volatile double *Uw = Mw + k * LD;
+    volatile double *zw = Uw + k * LD;
+    const double s2 = a.model[1], lnsig = a.model[2];
+    const int64_t stride = (int64_t)gridDim.x * 2;
+    for (int64_t i = (int64_t)blockIdx.x * 2 + wave; i < a.n; i += stride) {
+        double *g = a.G + i * kp;
+        double *bz = a.Bz + i * (k + 1);
+        for (int e = lane; e < kp; e += 64) {
+            int r = 0;
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            int c = e - r * (r + 1) / 2;
+            Mw[r * LD + c] = g[e] + (r == c ? s2 : 0.0);
+        }
+        const double bv = lane < k ? bz[lane] : 0.0;
+        double logdet, quad;
+        wave_cholesky(Mw, k, LD, lane, logdet);
+        const double z = wave_chol_solve(Mw, k, LD, lane, bv, quad);
+        if (lane < k) zw[lane] = z;
+        const double zz = gwave_sum(lane < k ? z * z : 0.0);
+        wave_chol_inverse(Mw, Uw, k, LD, lane);
+        const double tr = gwave_sum(lane < k ? Uw[lane * LD + lane] : 0.0);
+        const double wgt = a.w ? a.w[i] : 1.0;
+        const double xx = a.xx[i];
+        const int m = (int)a.mc[i];
+        const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, k);
+        if (a.em) {
+            // w P = w (z z^T + s2 M^-1), packed; lane c writes column c of every row a >= c
+            if (lane < k) {
+                for (int r = lane; r < k; ++r) g[r * (r + 1) / 2 + lane] = wgt * (zw[r] * z + s2 * Uw[r * LD + lane]);
+                bz[lane] = wgt * z;
+            }
+            if (lane == 0) {
+                bz[k] = wgt;
+                double *sc = a.sc + i * 4;
+                sc[0] = m > 0 ? wgt * s2 * ((double)k - s2 * tr) : 0.0;
+                sc[1] = m > 0 ? wgt * (xx - quad - s2 * zz) : 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = m > 0 ? 1.0 : 0.0;
+            }
+        } else {
+            if (lane < k) {
+                bz[lane] = z;  // unweighted state for the reconstruction pass
+                if (a.states) a.states[i * k + lane] = z;
+                for (int r = 0; r < k; ++r) {
+                    const double sv = s2 * Uw[r * LD + lane];
+                    if (a.covs) a.covs[(i * k + r) * k + lane] = sv;
+                    if (r >= lane) g[r * (r + 1) / 2 + lane] = sv;  // Sigma packed, for covariance diagonals
+                }
+            }
+            if (lane == 0) {
+                double *sc = a.sc + i * 4;
+                sc[0] = 0.0;
+                sc[1] = 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = 0.0;
+                if (a.llks) a.llks[i] = lk;
+            }
+        }
+    }
+}
+
+// strided column sum of sc[n][4] (+ sum of weights) into scal[8]; one block, deterministic
+__global__ void scal_reduce_kernel(const double *sc, const double *w, int64_t n, double *scal, int accumulate) {
+    __shared__ double red[256][5];
+    const int tid = threadIdx.x;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int64_t i = tid; i < n; i += 256) {
+        v[0] += sc[i * 4 + 0];
+        v[1] += sc[i * 4 + 1];
+        v[2] += sc[i * 4 + 2];
+        v[3] += sc[i * 4 + 3];
+        v[4] += w ? w[i] : 1.0;
+    }
+    for (int c = 0; c < 5; ++c) red[tid][c] = v[c];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o)
+            for (int c = 0; c < 5; ++c) red[tid][c] += red[tid + o][c];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double r[8] = {red[0][0], red[0][1], red[0][2], red[0][4], red[0][3], 0.0, 0.0, 0.0};
+        for (int c = 0; c < 8; ++c) scal[c] = accumulate ? scal[c] + r[c] : r[c];
+    }
+}
+
+// reconstruction / covariance diagonal from states (Bz, ld k+1) and packed Sigma (G)
+__global__ void recon_kernel(const double *X, int64_t ldx, int64_t n, int d, int k, const double *model,
+                             const double *Bz, const double *G, int mode, double *out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    const int64_t i = idx / d;
+    const int j = (int)(idx - i * d);
+    const double *c = model + MODEL_HDR + (int64_t)j * k;
+    const double mean = model[MODEL_HDR + (int64_t)d * k + j];
+    const double x = X[i * ldx + j];
+    const bool obs = __builtin_isfinite(x);
+    double o;
+    if (mode <= 1) {
+        double s = mean;
+        const double *z = Bz + i * (k + 1);
+        for (int a = 0; a < k; ++a) s += c[a] * z[a];
+        o = (mode == 1 && obs) ? x : s;
+    } else {
+        const double *sg = G + i * (int64_t)(k * (k + 1) / 2);
+        double v = 0.0;
+        for (int a = 0; a < k; ++a) {
+            double t = 0.0;
+            for (int b = 0; b < k; ++b) t += sg[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * c[b];
+            v += c[a] * t;
+        }
+        o = v + model[1];
+        if (mode == 3 && obs) o = 0.0;
+    }
+    out[idx] = o;
+}
+
+// ------------------------------------------------------------------ finalisation (runtime k)
+// One wave per dimension: S_j (+ tau I) c = cross_j by Cholesky in LDS; old row kept if not SPD.
+__global__ __launch_bounds__(128) void gen_rowsolve_kernel(const double *stats, const double *min, double *mout, int d,
+                                                           int k, double tau) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kp = k * (k + 1) / 2, LD = k | 1;
+    volatile double *Mw = gsm + (size_t)wave * (k * LD + 64);
+    const StatsLayout L(d, k);
+    for (int j = blockIdx.x * 2 + wave; j < d; j += gridDim.x * 2) {
+        const double *S = stats + L.S + (int64_t)j * kp;
+        for (int e = lane; e < kp; e += 64) {
+            int r = 0;
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            int c = e - r * (r + 1) / 2;
+            Mw[r * LD + c] = S[e] + (r == c ? tau : 0.0);
+        }
+        double logdet, quad;
+        const bool ok = wave_cholesky(Mw, k, LD, lane, logdet);
+        const double rhs = lane < k ? stats[L.cross + (int64_t)j * k + lane] : 0.0;
+        const double sol = wave_chol_solve(Mw, k, LD, lane, rhs, quad);
+        if (lane < k) {
+            const double old = min[MODEL_HDR + (int64_t)j * k + lane];
+            mout[MODEL_HDR + (int64_t)j * k + lane] = ok ? sol : old;  // :313-321 keep the old row
+        }
+    }
+}
+
+__global__ void gen_finalize_misc_kernel(const double *stats, const double *min, double *mout, int d, int k, int has_ig,
+                                         double alpha, double beta) {
+    __shared__ double red[256];
+    const StatsLayout L(d, k);
+    const int tid = threadIdx.x;
+    double ts = 0.0;
+    for (int j = tid; j < d; j += 256) ts += stats[L.totals + j];
+    red[tid] = ts;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const double totsum = red[0];
+    const double sq = stats[L.scalars + SC_SQERR], dv = stats[L.scalars + SC_DEVSQ];
+    const double s2new = has_ig ? ((sq + dv) / 2.0 + beta) / (totsum / 2.0 + alpha + 1.0) : (sq + dv) / totsum;
+    const double *Cold = min + MODEL_HDR;
+    const double *Mold = Cold + (int64_t)d * k;
+    double *Mnew = mout + MODEL_HDR + (int64_t)d * k;
+    for (int j = tid; j < d; j += 256) {
+        double cz = 0.0;
+        for (int a = 0; a < k; ++a) cz += Cold[(int64_t)j * k + a] * stats[L.U + (int64_t)j * k + a];
+        const double tot = stats[L.totals + j];
+        Mnew[j] = (tot > 0.0 ? (stats[L.sumx + j] - cz) / tot : 0.0) + Mold[j];
+    }
+    if (tid == 0) {
+        const double sig = sqrt(s2new);
+        mout[0] = sig;
+        mout[1] = sig * sig;
+        mout[2] = log(sig);
+        mout[3] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ host orchestration
+static int64_t gen_chunk(int k) {
+    const int64_t kp = (int64_t)k * (k + 1) / 2;
+    int64_t c = (int64_t)(1.5e9 / (8.0 * (double)(kp + k + 8)));  // ~1.5 GB of per-sample workspace
+    if (c > (1 << 20)) c = 1 << 20;
+    if (c < 4096) c = 4096;
+    return c;
+}
+
+size_t generic_workspace_bytes(int d, int k, int64_t n) {
+    const int64_t kp = (int64_t)k * (k + 1) / 2;
+    const int64_t c = std::min<int64_t>(gen_chunk(k), std::max<int64_t>(n, 1));
+    return sizeof(double) * (size_t)((int64_t)d * kp + c * (kp + (k + 1) + 2 + 4) + 64);
+}
+
+struct GenWs {
+    double *Q, *G, *Bz, *xx, *mc, *sc;
+    int64_t chunk;
+};
+static GenWs carve(void *ws, int d, int k, int64_t n) {
+    const int64_t kp = (int64_t)k * (k + 1) / 2;
+    GenWs w;
+    w.chunk = std::min<int64_t>(gen_chunk(k), std::max<int64_t>(n, 1));
+    double *p = static_cast<double *>(ws);
+    w.Q = p; p += (int64_t)d * kp;
+    w.G = p; p += w.chunk * kp;
+    w.Bz = p; p += w.chunk * (k + 1);
+    w.xx = p; p += w.chunk;
+    w.mc = p; p += w.chunk;
+    w.sc = p;
+    return w;
+}
+
+template <int AMODE>
+static hipError_t launch_gemm(const GemmArgs &g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64));
+    hipLaunchKernelGGL((gemm_kernel<AMODE>), grid, dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+static size_t solve_lds(int k) { return sizeof(double) * 2 * (size_t)(2 * k * (k | 1) + 64); }
+
+static hipError_t set_solve_lds(int k) {
+    static size_t cur = 0;
+    const size_t need = solve_lds(k);
+    if (need > cur) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        if (e != hipSuccess) return e;
+        cur = need;
+    }
+    return hipSuccess;
+}
+
+#define GTRY(expr)                        \
+    do {                                  \
+        hipError_t _e = (expr);           \
+        if (_e != hipSuccess) return _e;  \
+    } while (0)
+
+// E-step + statistics of all rows into stats (overwritten).  post == true: only the solve outputs.
+static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k,
+                              const double *model, bool em, double *stats,
+                              double *scal8, double *llks, double *states, double *covs, double *recon, int recon_mode,
+                              void *ws, int n_cu, hipStream_t s) {
+    const int64_t kp = (int64_t)k * (k + 1) / 2;
+    const StatsLayout L(d, k);
+    GenWs W = carve(ws, d, k, n);
+    const double *mean = model + MODEL_HDR + (int64_t)d * k;
+    const double *Cm = model + MODEL_HDR;
+    {
+        const int64_t tot = (int64_t)d * kp;
+        hipLaunchKernelGGL(qtab_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, model, d, k, W.Q);
+        GTRY(hipGetLastError());
+    }
+    GTRY(set_solve_lds(k));
+    if (em) GTRY(hipMemsetAsync(stats, 0, sizeof(double) * (size_t)L.len, s));
+    for (int64_t r0 = 0; r0 < n; r0 += W.chunk) {
+        const int64_t nc = std::min(W.chunk, n - r0);
+        const double *Xc = X + r0 * ldx;
+        const double *wc = w ? w + r0 : nullptr;
+        hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, s, Xc, ldx, nc, d, model, k,
+                           W.xx, W.mc);
+        GTRY(hipGetLastError());
+        GemmArgs g{};
+        g.X = Xc; g.ldx = ldx; g.mean = mean;
+        // G = Mask . Q
+        g.B = W.Q; g.ldb = kp; g.M = nc; g.N = kp; g.K = d;
+        g.out0 = W.G; g.ld0 = kp; g.ncols0 = kp; g.out1 = nullptr; g.ld1 = 0; g.accumulate = 0;
+        GTRY(launch_gemm<0>(g, s));
+        // b = X~ . C
+        g.B = Cm; g.ldb = k; g.N = k;
+        g.out0 = W.Bz; g.ld0 = k + 1; g.ncols0 = k;
+        GTRY(launch_gemm<1>(g, s));
+        SolveArgs a{};
+        a.G = W.G; a.Bz = W.Bz; a.xx = W.xx; a.mc = W.mc; a.w = wc; a.n = nc; a.k = k;
+        a.model = model; a.sc = W.sc; a.em = em ? 1 : 0;
+        a.llks = llks ? llks + r0 : nullptr;
+        a.states = states ? states + r0 * k : nullptr;
+        a.covs = covs ? covs + r0 * (int64_t)k * k : nullptr;
+        int sgrid = (int)std::min<int64_t>((nc + 1) / 2, (int64_t)n_cu);
+        if (sgrid < 1) sgrid = 1;
+        hipLaunchKernelGGL(solve_kernel, dim3(sgrid), dim3(128), solve_lds(k), s, a);
+        GTRY(hipGetLastError());
+        double *scal = em ? stats + L.scalars : scal8;
+        hipLaunchKernelGGL(scal_reduce_kernel, dim3(1), dim3(256), 0, s, W.sc, wc, nc, scal, (em || r0 > 0) ? 1 : 0);
+        GTRY(hipGetLastError());
+        if (em) {
+            // S += Mask^T . wP
+            g.B = W.G; g.ldb = kp; g.M = d; g.N = kp; g.K = nc;
+            g.out0 = stats + L.S; g.ld0 = kp; g.ncols0 = kp; g.accumulate = 1;
+            GTRY(launch_gemm<2>(g, s));
+            // [U | totals] += Mask^T . [wz | w]
+            g.B = W.Bz; g.ldb = k + 1; g.N = k + 1;
+            g.out0 = stats + L.U; g.ld0 = k; g.ncols0 = k; g.out1 = stats + L.totals; g.ld1 = 1;
+            GTRY(launch_gemm<2>(g, s));
+            // [cross | sumx] += X~^T . [wz | w]
+            g.out0 = stats + L.cross; g.out1 = stats + L.sumx;
+            GTRY(launch_gemm<3>(g, s));
+        } else if (recon) {
+            const int64_t tot = nc * d;
+            hipLaunchKernelGGL(recon_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, ldx, nc, d, k,
+                               model, W.Bz, W.G, recon_mode, recon + r0 * d);
+            GTRY(hipGetLastError());
+        }
+    }
+    return hipSuccess;
+}
+
+hipError_t generic_em_accumulate(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k,
+                                 const double *model, double *stats, void *ws, int n_cu, hipStream_t s) {
+    return generic_run(X, ldx, w, n, d, k, model, true, stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                       ws, n_cu, s);
+}
+
+hipError_t generic_post(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k, const double *model,
+                        double *scal8, double *llks, double *states, double *covs,
+                        double *recon, int recon_mode, void *ws, int n_cu, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(scal8, 0, sizeof(double) * 8, s);
+    return generic_run(X, ldx, w, n, d, k, model, false, nullptr, scal8, llks, states, covs, recon,
+                       recon_mode, ws, n_cu, s);
+}
+
+hipError_t generic_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
+                            int has_ig, double alpha, double beta, int n_cu, hipStream_t s) {
+    const size_t lds = sizeof(double) * 2 * (size_t)(k * (k | 1) + 64);
+    static size_t cur = 0;
+    if (lds > cur) {
+        GTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&gen_rowsolve_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cur = lds;
+    }
+    int grid = std::min((d + 1) / 2, n_cu * 2);
+    hipLaunchKernelGGL(gen_rowsolve_kernel, dim3(grid), dim3(128), lds, s, stats, model_in, model_out, d, k, tau);
+    GTRY(hipGetLastError());
+    hipLaunchKernelGGL(gen_finalize_misc_kernel, dim3(1), dim3(256), 0, s, stats, model_in, model_out, d, k, has_ig,
+                       alpha, beta);
+    return hipGetLastError();
+}
+
+}  // namespace ppca

@@ -56,6 +56,17 @@ hipError_t launch_fill(double *p, int64_t n, double v, hipStream_t s);
 // debug: C/D layout probe of v_mfma_f64_16x16x4_f64 (out: 16 x 16 row-major)
 hipError_t launch_mfma_probe(const double *a16x4, const double *b4x16, double *out16x16, hipStream_t s);
 
+// generic split pipeline (ppca_generic.hip): any d, k <= GENERIC_MAX_K
+constexpr int GENERIC_MAX_K = 64;
+size_t generic_workspace_bytes(int d, int k, int64_t n);
+hipError_t generic_em_accumulate(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k,
+                                 const double *model, double *stats, void *ws, int n_cu, hipStream_t s);
+hipError_t generic_post(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k, const double *model,
+                        double *scal8, double *llks, double *states, double *covs, double *recon, int recon_mode,
+                        void *ws, int n_cu, hipStream_t s);
+hipError_t generic_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
+                            int has_ig, double alpha, double beta, int n_cu, hipStream_t s);
+
 // mixture helpers
 // llk: [n_models][n]; logw: [n_models]; w nullable.  Writes u: [n_models][n] =
 // ln w_i + log posterior_ic (-inf when w_i <= 0) and lse[n] (mixture llk per sample).

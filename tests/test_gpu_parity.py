@@ -258,3 +258,54 @@ def test_full_size_properties(P):
     ob = np.isfinite(x)
     np.testing.assert_array_equal(ex[ob], x[ob])
     assert np.isfinite(ex).all()
+
+
+@pytest.mark.parametrize("n,d,k,mp,block", [(600, 300, 4, 0.3, False), (800, 200, 16, 0.2, False),
+                                            (257, 1024, 64, 0.5, True), (90, 40, 12, 0.4, False)])
+def test_generic_pipeline_matches_oracle(P, oracle, n, d, k, mp, block):
+    """Shapes outside the fused kernel (d > 256 or k > 10) run the split pipeline
+    (ppca_generic.hip); BASELINE config 4 (d = 1024, k = 64, 50 % block-masked) at oracle-sized N."""
+    from ppca_rs_amd import _lib
+
+    assert _lib.lib().ppca_path_kind(d, k) == 0
+    rng = np.random.default_rng(d + k)
+    if block:  # one cyclic run of d/2 masked dims per sample (SURVEY 8d, cfg 4)
+        x, _, _ = oracle.synth(n, d, k, 0.0, 700 + d)
+        for i in range(n):
+            st = rng.integers(0, d)
+            x[i, (st + np.arange(d // 2)) % d] = np.nan
+    else:
+        x, _, _ = oracle.synth(n, d, k, mp, 700 + d)
+    x[1] = np.nan
+    w = rng.uniform(0.5, 1.5, n)
+    c, mu, s = 0.3 * rng.standard_normal((d, k)), 0.1 * rng.standard_normal(d), 0.9
+    ds, m = P.Dataset(x, w), P.PPCAModel(s, c, mu)
+    L = _lib.lib().ppca_stats_len(d, k)
+    got = np.empty(L)
+    _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
+    want = oracle.stats(x, s, c, mu, w)
+    kp = k * (k + 1) // 2
+    bounds = [0, d * k, d * k + d * kp, 2 * d * k + d * kp, 2 * d * k + d * kp + d, 2 * d * k + d * kp + 2 * d, L]
+    for name, a, b in zip(["cross", "S", "U", "sumx", "totals", "scalars"], bounds[:-1], bounds[1:]):
+        assert _rel(got[a:b], want[a:b]) < 1e-8, name
+    assert _rel(m.llks(ds), oracle.llks(x, s, c, mu)) < 1e-9
+    assert abs(m.llk(ds) - oracle.llk(x, s, c, mu, w)) < 1e-9 * abs(oracle.llk(x, s, c, mu, w))
+    inf = m.infer(ds)
+    st, cv = oracle.infer(x, s, c, mu)
+    assert _rel(inf.states(), st) < 1e-7 and _rel(np.array(inf.covariances()), cv) < 1e-7
+    assert _rel(m.smooth(ds).numpy(), oracle.reconstruct(x, s, c, mu, "smooth")) < 1e-8
+    ex = m.extrapolate(ds).numpy()
+    assert _rel(ex, oracle.reconstruct(x, s, c, mu, "extrapolate")) < 1e-8
+    np.testing.assert_array_equal(ex[np.isfinite(x)], x[np.isfinite(x)])
+    for _ in range(2):
+        want_llk = oracle.llk(x, s, c, mu, w)
+        s, c, mu = oracle.iterate(x, s, c, mu, w)
+        m, llk = m.iterate_with_llk(ds)
+        assert abs(llk - want_llk) < RTOL * 1e-3 * abs(want_llk)
+        assert abs(m.isotropic_noise - s) < RTOL * s
+        assert _rel(m.transform, c) < RTOL and _rel(m.mean, mu) < RTOL
+    diag = m.infer(ds).smoothed_covariances_diagonal(m).numpy()
+    _lib_h = C.c_void_p()
+    _lib.check(_lib.lib().ppca_covariance_diagonal(ds._ctx.handle, ds._h, m._device(ds._ctx).h, 0, C.byref(_lib_h)))
+    dev_diag = P.Dataset._wrap(_lib_h, ds._ctx).numpy()
+    assert _rel(dev_diag, diag) < 1e-7
