@@ -215,6 +215,10 @@ int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, con
  * (16 x 16) written through the C/D lane map the kernels assume (unit test). */
 int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const double *b4x16, double *out16x16);
 
+/* One v_mfma_i32_16x16x64_i8 on raw per-lane operand registers (a_regs, b_regs: [64 lanes][16 bytes];
+ * out_regs: [64 lanes][4 i32]) -- pins the operand / result lane maps of the int8 Gram path (unit test). */
+int ppca_debug_mfma_i8_probe(ppca_ctx *ctx, const int8_t *a_regs, const int8_t *b_regs, int32_t *out_regs);
+
 #ifdef __cplusplus
 }
 #endif

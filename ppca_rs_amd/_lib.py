@@ -100,6 +100,7 @@ SIGNATURES = {
     "ppca_mix_em_step": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, C.POINTER(Prior), c_void_pp, C.c_void_p, c_double_p]),
     "ppca_mix_llk": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, c_double_p, C.c_void_p, C.c_void_p]),
     "ppca_debug_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppca_debug_mfma_i8_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -76,6 +76,8 @@ struct ppca_ctx {
     BufRef scal;  // post-pass scalars: [grid][8] partials + 8 reduced
     size_t scal_cap = 0;
     BufRef work;  // 2048 doubles for reductions
+    BufRef qtab;  // int8 Gram slice table + scales of the model being processed
+    size_t qtab_cap = 0;
     BufRef gws;   // workspace of the generic split pipeline
     size_t gws_cap = 0;
 };
@@ -539,6 +541,9 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
     a.d = ds->d;
     a.model = model->p();
     a.part = static_cast<double *>(ctx->part->p);
+    if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
+    a.qscale = static_cast<double *>(ctx->qtab->p);
+    a.qtab = reinterpret_cast<signed char *>(a.qscale + 64);
 #ifdef PPCA_PHASE_TIMING
     BufRef dbg;
     if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 8, &dbg)) return rc;
@@ -777,6 +782,9 @@ static int run_post(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, do
         a.covs = covs_dev;
         a.recon = recon_dev;
         a.recon_mode = recon_mode;
+        if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
+        a.qscale = static_cast<double *>(ctx->qtab->p);
+        a.qtab = reinterpret_cast<signed char *>(a.qscale + 64);
         HIP_TRY(launch_pass_post(model->k, grid, a, ctx->stream));
         HIP_TRY(launch_reduce_partials(scal, grid, 8, scal + (size_t)grid * 8, ctx->stream));
     }
@@ -988,6 +996,21 @@ extern "C" int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const d
     HIP_TRY(hipMemcpyAsync(p + 64, b4x16, sizeof(double) * 64, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(launch_mfma_probe(p, p + 64, p + 128, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out16x16, p + 128, sizeof(double) * 256, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
+extern "C" int ppca_debug_mfma_i8_probe(ppca_ctx *ctx, const int8_t *a_regs, const int8_t *b_regs, int32_t *out_regs) {
+    if (!ctx || !a_regs || !b_regs || !out_regs) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = use_device(ctx)) return rc;
+    BufRef buf;
+    if (int rc = dev_alloc(1024 + 1024 + 1024, &buf)) return rc;
+    char *p = static_cast<char *>(buf->p);
+    HIP_TRY(hipMemcpyAsync(p, a_regs, 1024, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(p + 1024, b_regs, 1024, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_mfma_i8_probe(reinterpret_cast<int *>(p), reinterpret_cast<int *>(p + 1024),
+                                 reinterpret_cast<int *>(p + 2048), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_regs, p + 2048, 1024, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PPCA_OK;
 }

@@ -36,12 +36,15 @@ struct PassArgs {
     double *covs;         // n x k x k
     double *recon;        // n x d
     int recon_mode;       // 0 smooth, 1 extrapolate, 2 smoothed cov diag, 3 extrapolated cov diag
+    signed char *qtab;    // int8 Gram slice table of the current model (written by the launcher's qprep)
+    double *qscale;       // its 64 dequantisation multipliers
     double *dbg;          // diagnostic builds (-DPPCA_PHASE_TIMING): [grid][4] phase cycle sums
 };
 
 // Number of workgroups the fused pass wants for n rows on a device with n_cu CUs.
 int fused_grid(int64_t n, int n_cu);
 size_t fused_lds_bytes(int k);
+size_t fused_qtab_bytes();  // device scratch the fused launchers need in PassArgs::qtab / qscale
 // Launchers.  Return hipSuccess or the launch error.
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s);
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);
@@ -54,6 +57,7 @@ hipError_t launch_synth(const double *c_dev, const double *mean_dev, double *z_w
 hipError_t launch_column_presence(const double *X, int64_t ldx, int64_t n, int d, int *present, hipStream_t s);
 hipError_t launch_fill(double *p, int64_t n, double v, hipStream_t s);
 // debug: C/D layout probe of v_mfma_f64_16x16x4_f64 (out: 16 x 16 row-major)
+hipError_t launch_mfma_i8_probe(const int *a, const int *b, int *out, hipStream_t s);
 hipError_t launch_mfma_probe(const double *a16x4, const double *b4x16, double *out16x16, hipStream_t s);
 
 // generic split pipeline (ppca_generic.hip): any d, k <= GENERIC_MAX_K

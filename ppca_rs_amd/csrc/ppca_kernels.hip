@@ -57,9 +57,73 @@ __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// ------------------------------------------------------------------ int8-sliced Gram operand
+// G_i = sum_j m_ij vech(c_j c_j^T) has one EXACT operand (the 0/1 mask), so the other one can be
+// split into QS signed 7-bit digits of a per-column fixed-point representation and contracted on
+// v_mfma_i32_16x16x64_i8 with exact integer accumulation:
+//   Q[j][c] = c_ja c_jb  ~  2^E_c 2^-(7 QS - 2) sum_s 128^s dig_s[j][c],   dig_s in [-64, 63],
+// E_c = exponent of max_j |Q[j][c]| (|Q| < 2^E_c).  QS balanced digits span (-0.504, +0.496) 128^QS, so
+// the integers are kept below 2^(7 QS - 2): with QS = 8 that is 54 bits under the column maximum,
+// finer than the fp64 rounding of the products themselves.
+constexpr int QS = 8;
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
+template <int K>
+constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
+
+// qtab: [NTP][QS][4 k-chunks][64 lanes][16 bytes]; lane = 16 (dim/16 % 4) + (col % 16), byte = dim % 16
+// qscale: [64] dequantisation multipliers 2^(E_c - (7 QS - 2)).  One workgroup, thread = dim.
+template <int K>
+__global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, signed char *qtab, double *qscale) {
+    constexpr int KP = Cfg<K>::KP, NTP = Cfg<K>::NTP;
+    __shared__ unsigned long long cmax[16 * NTP];
+    const int j = threadIdx.x;
+    for (int c = j; c < 16 * NTP; c += 256) cmax[c] = 0ull;
+    __syncthreads();
+    double cj[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) cj[a] = (j < d) ? model[MODEL_HDR + (int64_t)j * K + a] : 0.0;
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const double q = fabs(cj[a] * cj[b]);
+            if (q > 0.0 && q < 1.0e300) atomicMax(&cmax[tri(a, b)], (unsigned long long)__double_as_longlong(q));
+        }
+    __syncthreads();
+    if (j < 16 * NTP) {
+        int e = 0;
+        const double mx = __longlong_as_double((long long)cmax[j]);
+        if (mx > 0.0) (void)frexp(mx, &e);
+        qscale[j] = ldexp(1.0, e - (7 * QS - 2));
+    }
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int c = tri(a, b);
+            int e = 0;
+            const double mx = __longlong_as_double((long long)cmax[c]);
+            if (mx > 0.0) (void)frexp(mx, &e);
+            double q = cj[a] * cj[b];
+            if (!(fabs(q) < 1.0e300)) q = 0.0;
+            long long I = llrint(ldexp(q, (7 * QS - 2) - e));  // |I| <= 2^(7 QS - 2)
+            const int t = c >> 4, lane = 16 * ((j >> 4) & 3) + (c & 15), kc = j >> 6;
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const int dig = (int)((I + 64) & 127) - 64;
+                I = (I - dig) >> 7;
+                qtab[((((size_t)t * QS + s) * 4 + kc) * 64 + lane) * 16 + (j & 15)] = (signed char)dig;
+            }
+        }
+    // pad columns (c >= KP) of the last tile stay zero: the table is cleared by the launcher
+    (void)KP;
+}
+
 // NW = waves per workgroup: 4 (one wave per SIMD, 512 registers each) or 8 (two waves per SIMD,
 // 256 registers each, every wave owning half as many accumulator tiles).
-template <int K, bool EM, int NW>
+// GI8: Gram on the int8 MFMA (wave t <-> packed-column tile t) instead of fp64 MFMA.
+template <int K, bool EM, int NW, bool GI8>
 __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     using cfg = Cfg<K>;
     constexpr int KP = cfg::KP, NTP = cfg::NTP, NTM = cfg::NTM, B = cfg::B, XS = cfg::XS, CS = cfg::CS,
@@ -73,6 +137,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     constexpr int RT = 16 / NW;          // accumulator row tiles (16 dims each) per wave in P4
     constexpr int DW = cfg::DP / NW;     // dims owned by a wave in P4
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(!GI8 || (NW == 4 && NTP <= 4), "int8 Gram: one wave per packed-column tile");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Xs = sm + cfg::OFF_X;
     double *Cs = sm + cfg::OFF_C;
@@ -209,6 +274,34 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         PPCA_STAMP(0)
         // ------------------------------------------------------------ P2
         {
+            // int8 Gram: the slice table of this wave's column tile (QS x 4 fragments of 16 B per lane,
+            // L2-resident) streams through registers in three digit groups, high to low: {7,6} and
+            // {5,4,3} are requested now and land behind the fp64 b = X~ C loop, {2,1,0} is requested
+            // while the first group is contracted.
+            static_assert(!GI8 || QS == 8, "digit grouping below assumes 8 slices");
+            // buffer loads: one scalar resource for the table, a scalar offset per fragment and ONE lane
+            // offset register -- no per-load vector addresses for hipcc to keep alive (and spill)
+            const __amdgpu_buffer_rsrc_t qrsrc =
+                __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
+            auto ldq = [&](int sl, int kc) {
+                typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane * 16, ((wave * QS + sl) * 4 + kc) * 1024, 0);
+                return i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+            };
+            i4_t qbA[GI8 ? 2 : 1][4], qbB[GI8 ? 3 : 1][4], qbC[GI8 ? 3 : 1][4];
+            const bool gram_wave = GI8 && wave < NTP;
+            if constexpr (GI8) {
+                if (gram_wave) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) qbA[u][kc] = ldq(6 + u, kc);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) qbB[u][kc] = ldq(3 + u, kc);
+                }
+            }
             const int rt = wave & 1, kq = wave >> 1;
             const int si = 16 * rt + l15;
             unsigned long long mw[WPS];
@@ -231,17 +324,75 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 const double ax = xrow[4 * s];
-                const double am = ((mw[s / 16] >> (4 * (s & 15) + l4)) & 1ull) ? 1.0 : 0.0;
+                if constexpr (!GI8) {
+                    const double am = ((mw[s / 16] >> (4 * (s & 15) + l4)) & 1ull) ? 1.0 : 0.0;
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) acc[t] = mfma(am, cpa[t][4 * s * CS] * cpb[t][4 * s * CS], acc[t]);
+                    for (int t = 0; t < NTP; ++t)
+                        acc[t] = mfma(am, cpa[t][4 * s * CS] * cpb[t][4 * s * CS], acc[t]);
+                }
                 acc[NTP] = mfma(ax, cpc[4 * s * CS], acc[NTP]);
+            }
+            if constexpr (GI8) {
+                if (gram_wave) {
+                    // A = mask bytes: lane (sample = 16 rt + l15, dims 64 kc + 16 l4 .. +15); 4 bits -> 4 bytes
+                    // by one multiply: (x * 0x204081) & 0x01010101 puts bit i of x into byte i.
+                    i4_t af[2][4];
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) {
+                            const unsigned bits = (unsigned)(Ms[(16 * rt2 + l15) * 4 + kc] >> (16 * l4)) & 0xFFFFu;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
+                        }
+                    // one digit group: contract, then fold the (exact) integer digit sums -- |sum| <= 2^14,
+                    // so up to three digits fit one i32 -- into the running fp64 value, Horner in 128^3
+                    double v[2][4];
+                    auto group = [&](const i4_t(*qb)[4], int cnt, bool first) {
+#pragma unroll
+                        for (int rt2 = 0; rt2 < 2; ++rt2) {
+                            i4_t ia[3];
+#pragma unroll
+                            for (int u = 0; u < 3; ++u) {
+                                if (u >= cnt) continue;
+                                ia[u] = i4_t{0, 0, 0, 0};
+#pragma unroll
+                                for (int kc = 0; kc < 4; ++kc)
+                                    ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt2][kc], qb[u][kc], ia[u], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                int part = 0;
+#pragma unroll
+                                for (int u = 2; u >= 0; --u)
+                                    if (u < cnt) part = part * 128 + ia[u][r];
+                                v[rt2][r] = first ? (double)part : v[rt2][r] * 2097152.0 + (double)part;
+                            }
+                        }
+                    };
+                    group(qbA, 2, true);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) qbC[u][kc] = ldq(u, kc);
+                    group(qbB, 3, false);
+                    group(qbC, 3, false);
+                    const double qs = p.qscale[16 * wave + l15];
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)  // C/D map of the 16x16 integer MFMA: row = 4 (lane >> 4) + reg
+                            Gp[(16 * rt2 + 4 * l4 + r) * GS + 16 * wave + l15] = v[rt2][r] * qs;
+                }
             }
             // K-split partials -> two buffers, summed in a fixed order (deterministic):
             // G = (p0 [+ p2]) + (p1 [+ p3]); the bracketed terms are added in place by their owner
             double *g = Gp + (kq & 1) * B * GS;
+            constexpr int T0 = GI8 ? NTP : 0;  // int8 Gram: only the b tile comes from the fp64 accumulators
             if (kq < 2) {
 #pragma unroll
-                for (int t = 0; t < NTM; ++t)
+                for (int t = T0; t < NTM; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) g[(16 * rt + l4 + 4 * r) * GS + 16 * t + l15] = acc[t][r];
             }
@@ -249,7 +400,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 __syncthreads();
                 if (kq >= 2) {
 #pragma unroll
-                    for (int t = 0; t < NTM; ++t)
+                    for (int t = T0; t < NTM; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) g[(16 * rt + l4 + 4 * r) * GS + 16 * t + l15] += acc[t][r];
                 }
@@ -270,7 +421,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             const int m = mcnt[i];
             double *wrow = Ws + i * WS;
             Posterior<K> post;
-            const double logdet = post.factor([&](int e) { return g0[e] + g1[e]; }, s2);
+            const double logdet = post.factor([&](int e) { return GI8 ? g0[e] : g0[e] + g1[e]; }, s2);
             double z[K], quad, zz;
             post.solve([&](int a) { return g0[16 * NTP + a] + g1[16 * NTP + a]; }, z, quad, zz);
             double trpart = 0.0;
@@ -644,18 +795,36 @@ size_t fused_lds_bytes(int k) {
     return 0;
 }
 
-template <int K, bool EM, int NW>
+template <int K, bool EM, int NW, bool GI8>
 static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
     const size_t lds = sizeof(double) * Cfg<K>::LDS_DOUBLES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM, NW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM, NW, GI8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((pass_kernel<K, EM, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
+    if constexpr (GI8) {
+        // slice table of the current model (device-side, no host sync): 1 workgroup, ~10 us
+        hipError_t e = hipMemsetAsync(a.qtab, 0, qtab_bytes<K>(), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((qprep_kernel<K>), dim3(1), dim3(256), 0, s, a.model, a.d, a.qtab, a.qscale);
+    }
+    hipLaunchKernelGGL((pass_kernel<K, EM, NW, GI8>), dim3(grid), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
+}
+
+size_t fused_qtab_bytes() { return qtab_bytes<FUSED_MAX_K>() + 64 * sizeof(double); }
+
+// Gram engine: int8-sliced MFMA unless PPCA_GRAM_FP64=1.
+static bool gram_i8() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PPCA_GRAM_FP64");
+        v = (e && atoi(e) == 1) ? 0 : 1;
+    }
+    return v == 1;
 }
 
 // Waves per workgroup of the EM pass: 4 (one per SIMD, 512 registers each).  PPCA_FUSED_WAVES=8
@@ -686,15 +855,21 @@ static int em_waves() {
     }
 
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
-    if (em_waves() == 4) {
-        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4>(grid, a, s)));
+    if (em_waves() == 8) {
+        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 8, false>(grid, a, s)));
+    } else if (gram_i8()) {
+        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4, true>(grid, a, s)));
     } else {
-        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 8>(grid, a, s)));
+        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4, false>(grid, a, s)));
     }
     return hipErrorInvalidValue;
 }
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s) {
-    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4>(grid, a, s)));
+    if (gram_i8()) {
+        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, true>(grid, a, s)));
+    } else {
+        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, false>(grid, a, s)));
+    }
     return hipErrorInvalidValue;
 }
 
@@ -736,6 +911,22 @@ hipError_t launch_column_presence(const double *X, int64_t ldx, int64_t n, int d
 hipError_t launch_fill(double *p, int64_t n, double v, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+// raw operand/result registers of one v_mfma_i32_16x16x64_i8: a, b: [64 lanes][16 bytes]; out: [64][4]
+__global__ void mfma_i8_probe_kernel(const int *a, const int *b, int *out) {
+    const int lane = threadIdx.x;
+    i4_t av, bv, acc = {0, 0, 0, 0};
+    for (int u = 0; u < 4; ++u) {
+        av[u] = a[lane * 4 + u];
+        bv[u] = b[lane * 4 + u];
+    }
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u) out[lane * 4 + u] = acc[u];
+}
+hipError_t launch_mfma_i8_probe(const int *a, const int *b, int *out, hipStream_t s) {
+    hipLaunchKernelGGL(mfma_i8_probe_kernel, dim3(1), dim3(64), 0, s, a, b, out);
     return hipGetLastError();
 }
 
