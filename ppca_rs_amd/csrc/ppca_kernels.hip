@@ -224,7 +224,15 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #else
 #define PPCA_STAMP(i)
 #endif
+    const int lane_entry = lane;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // The lane index is made opaque once per tile: everything derived from it (LDS addresses, shift
+        // counts, column maps) is then recomputed per tile -- a few integer ops -- instead of being
+        // hoisted out of the loop by LICM and parked in (spilled) registers for the whole kernel.
+        int lane = lane_entry;
+        asm volatile("" : "+v"(lane));
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int colb = (l15 < K) ? l15 : K;
         // ------------------------------------------------------------ P1
         {
             // Wave-uniform results (mask words, popcounts, row sums) are gathered into the lane that
