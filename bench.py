@@ -176,7 +176,7 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": PMC_BYTES_PER_SAMPLE * rows_local if (d, k) == (256, 10) else None,
                 "traffic_unit": "bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01/README.md)",
-                "kernel": "ppca::pass_kernel<10, true>",
+                "kernel": "ppca::pass_kernel<10, true, 4, true>",
                 "kernel_avg_ms": kern_avg_ms,
                 "kernel_launches": launches,
                 "algorithmic_bytes_per_launch": bytes_launch,

@@ -72,10 +72,11 @@ template <int K>
 constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
 
 // qtab: [NTP][QS][4 k-chunks][64 lanes][16 bytes]; lane = 16 (dim/16 % 4) + (col % 16), byte = dim % 16
-// qscale: [64] dequantisation multipliers 2^(E_c - (7 QS - 2)).  One workgroup, thread = dim.
+// qscale: [64] dequantisation multipliers 2^(E_c - (7 QS - 2)).
+// Step 1 (one workgroup, thread = dim): column maxima -> qscale.
 template <int K>
-__global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, signed char *qtab, double *qscale) {
-    constexpr int KP = Cfg<K>::KP, NTP = Cfg<K>::NTP;
+__global__ __launch_bounds__(256) void qmax_kernel(const double *model, int d, double *qscale) {
+    constexpr int NTP = Cfg<K>::NTP;
     __shared__ unsigned long long cmax[16 * NTP];
     const int j = threadIdx.x;
     for (int c = j; c < 16 * NTP; c += 256) cmax[c] = 0ull;
@@ -87,8 +88,13 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     for (int a = 0; a < K; ++a)
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
-            const double q = fabs(cj[a] * cj[b]);
-            if (q > 0.0 && q < 1.0e300) atomicMax(&cmax[tri(a, b)], (unsigned long long)__double_as_longlong(q));
+            double q = fabs(cj[a] * cj[b]);
+            if (!(q < 1.0e300)) q = 0.0;
+            // wave-level maximum first (non-negative doubles order like their bit patterns), then one
+            // LDS atomic per wave instead of 256 contending ones
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q = fmax(q, __shfl_xor(q, o, 64));
+            if ((j & 63) == 0 && q > 0.0) atomicMax(&cmax[tri(a, b)], (unsigned long long)__double_as_longlong(q));
         }
     __syncthreads();
     if (j < 16 * NTP) {
@@ -97,27 +103,43 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
         if (mx > 0.0) (void)frexp(mx, &e);
         qscale[j] = ldexp(1.0, e - (7 * QS - 2));
     }
+}
+
+// Step 2: one thread per (column tile, slice-independent) 16-byte fragment row: thread -> (t, kc, lane),
+// i.e. 16 dims x one column; writes its 16 digits of every slice as one 16-byte store per slice.
+template <int K>
+__global__ __launch_bounds__(256) void qdigits_kernel(const double *model, int d, const double *qscale,
+                                                      signed char *qtab) {
+    constexpr int KP = Cfg<K>::KP, NTP = Cfg<K>::NTP;
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // ((t * 4 + kc) * 64 + lane)
+    if (idx >= NTP * 4 * 64) return;
+    const int lane = idx & 63, kc = (idx >> 6) & 3, t = idx >> 8;
+    const int c = 16 * t + (lane & 15);
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= c) ++a;
+    const int b = c - a * (a + 1) / 2;
+    const int j0 = 64 * kc + 16 * (lane >> 4);
+    int ex = 0;
+    (void)frexp(qscale[c < 16 * NTP ? c : 0], &ex);  // qscale = 2^(E - (7 QS - 2)) = 0.5 * 2^(ex)
+    const int shift = -(ex - 1);                       // multiply by 2^(7 QS - 2 - E)
+    union { signed char b8[QS][16]; i4_t v[QS]; } dg;
 #pragma unroll
-    for (int a = 0; a < K; ++a)
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = j0 + jj;
+        double q = 0.0;
+        if (c < KP && j < d) q = model[MODEL_HDR + (int64_t)j * K + a] * model[MODEL_HDR + (int64_t)j * K + b];
+        if (!(fabs(q) < 1.0e300)) q = 0.0;
+        long long I = llrint(ldexp(q, shift));  // |I| <= 2^(7 QS - 2)
 #pragma unroll
-        for (int b = 0; b <= a; ++b) {
-            const int c = tri(a, b);
-            int e = 0;
-            const double mx = __longlong_as_double((long long)cmax[c]);
-            if (mx > 0.0) (void)frexp(mx, &e);
-            double q = cj[a] * cj[b];
-            if (!(fabs(q) < 1.0e300)) q = 0.0;
-            long long I = llrint(ldexp(q, (7 * QS - 2) - e));  // |I| <= 2^(7 QS - 2)
-            const int t = c >> 4, lane = 16 * ((j >> 4) & 3) + (c & 15), kc = j >> 6;
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                const int dig = (int)((I + 64) & 127) - 64;
-                I = (I - dig) >> 7;
-                qtab[((((size_t)t * QS + s) * 4 + kc) * 64 + lane) * 16 + (j & 15)] = (signed char)dig;
-            }
+        for (int sl = 0; sl < QS; ++sl) {
+            const int dig = (int)((I + 64) & 127) - 64;
+            I = (I - dig) >> 7;
+            dg.b8[sl][jj] = (signed char)dig;
         }
-    // pad columns (c >= KP) of the last tile stay zero: the table is cleared by the launcher
-    (void)KP;
+    }
+#pragma unroll
+    for (int sl = 0; sl < QS; ++sl)
+        reinterpret_cast<i4_t *>(qtab)[(((size_t)t * QS + sl) * 4 + kc) * 64 + lane] = dg.v[sl];
 }
 
 // NW = waves per workgroup: 4 (one wave per SIMD, 512 registers each) or 8 (two waves per SIMD,
@@ -606,13 +628,29 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     }
 }
 
-// out[e] = sum over workgroup partials in fixed order (deterministic).
-__global__ void reduce_partials_kernel(const double *part, int grid_parts, int64_t len, double *out) {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= len) return;
-    double s = 0.0;
-    for (int g = 0; g < grid_parts; ++g) s += part[(int64_t)g * len + e];
-    out[e] = s;
+// out[e] = sum over workgroup partials in a fixed order (deterministic): four threads per element
+// each sum a contiguous quarter of the partials, the quarters are combined as (q0 + q1) + (q2 + q3).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *part, int grid_parts, int64_t len,
+                                                             double *out) {
+    __shared__ double red[4][64];
+    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 64 + l;
+    const int per = (grid_parts + 3) / 4;
+    const int p0 = g * per, p1 = (p0 + per < grid_parts) ? p0 + per : grid_parts;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (e < len) {
+        int q = p0;
+        for (; q + 4 <= p1; q += 4) {  // four independent chains, recombined in a fixed order
+            s0 += part[(int64_t)q * len + e];
+            s1 += part[(int64_t)(q + 1) * len + e];
+            s2 += part[(int64_t)(q + 2) * len + e];
+            s3 += part[(int64_t)(q + 3) * len + e];
+        }
+        for (; q < p1; ++q) s0 += part[(int64_t)q * len + e];
+    }
+    red[g][l] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < len) out[e] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
 
 // M-step finalisation (ppca_model.rs:307-322, :360-377) -- one workgroup.
@@ -814,10 +852,9 @@ static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
         attr_set = true;
     }
     if constexpr (GI8) {
-        // slice table of the current model (device-side, no host sync): 1 workgroup, ~10 us
-        hipError_t e = hipMemsetAsync(a.qtab, 0, qtab_bytes<K>(), s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((qprep_kernel<K>), dim3(1), dim3(256), 0, s, a.model, a.d, a.qtab, a.qscale);
+        // slice table of the current model (device-side, no host sync): column maxima, then digits
+        hipLaunchKernelGGL((qmax_kernel<K>), dim3(1), dim3(256), 0, s, a.model, a.d, a.qscale);
+        hipLaunchKernelGGL((qdigits_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab);
     }
     hipLaunchKernelGGL((pass_kernel<K, EM, NW, GI8>), dim3(grid), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
@@ -882,7 +919,7 @@ hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s) {
-    int blocks = (int)((len + 255) / 256);
+    int blocks = (int)((len + 63) / 64);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, part, grid_parts, len, out);
     return hipGetLastError();
 }
