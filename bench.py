@@ -71,12 +71,14 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--n", "--samples", dest="n", type=int, default=10_000_000)
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mask", type=float, default=0.3)
     ap.add_argument("--cpu-rows", type=int, default=100_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU tests)")
+    ap.add_argument("--dump-model", default=None, help="rank 0 writes the final model to this .npz (tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,15 +92,20 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)  # several ranks may share a GPU only with --backend gloo (tests)
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import ppca_rs_amd as P
     from ppca_rs_amd import _lib
     from ppca_rs_amd.distributed import ShardedEM, shard_bounds
 
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(dev_index)
     _lib.set_default_context(ctx)
 
     n, d, k = args.n, args.d, args.k
@@ -141,6 +148,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     llk_last = em.llk_of_previous()
+    if args.dump_model and rank == 0:
+        fm = em.model()
+        np.savez(args.dump_model, sigma=fm.isotropic_noise, transform=fm.transform, mean=fm.mean, llk=llk_last)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -191,6 +201,7 @@ def main() -> None:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
+    em.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

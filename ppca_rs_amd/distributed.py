@@ -64,8 +64,11 @@ def allreduce_finalize_host(model: PPCAModel, local_stats: np.ndarray, prior: Op
 
 class ShardedEM:
     """Device flavour: holds this rank's shard and a ping-pong pair of device models;
-    `step()` enqueues pass -> all-reduce -> finalise on torch's current stream without
-    any host synchronisation."""
+    `step()` enqueues pass -> all-reduce -> finalise on ONE dedicated torch stream, which is
+    also the stream the library launches on, without any host synchronisation.  (A dedicated
+    stream, not torch's default one: the legacy default stream has handle 0, which the C-ABI
+    reads as "create your own stream" -- the collective would then not be ordered after the
+    kernels.)"""
 
     def __init__(self, shard: Dataset, start: PPCAModel, prior: Optional[Prior] = None, group=None):
         import torch
@@ -74,32 +77,48 @@ class ShardedEM:
         self.shard, self.prior, self.group = shard, prior, group
         self.ctx = shard._ctx
         self.d, self.k = start.output_size, start.state_size
-        self.stream = torch.cuda.current_stream()
-        self.ctx.set_stream(self.stream.cuda_stream)
-        self.stats = torch.zeros(stats_len(self.d, self.k), dtype=torch.float64, device="cuda")
+        self.stream = torch.cuda.Stream()
+        assert self.stream.cuda_stream != 0
+        with torch.cuda.stream(self.stream):
+            self.stats = torch.zeros(stats_len(self.d, self.k), dtype=torch.float64, device="cuda")
         self.cur = start._device(self.ctx)
         h = C.c_void_p()
         check(lib().ppca_model_alloc(self.ctx.handle, self.d, self.k, C.byref(h)))
         self.nxt = _DevModel(h)
         self._pref, self._keep = _prior_ref(prior)
         self._start = start  # keeps the first device model alive
+        torch.cuda.synchronize()
+        self.ctx.set_stream(self.stream.cuda_stream)
 
     def step(self) -> None:
         import torch.distributed as dist
 
-        check(lib().ppca_em_accumulate(self.ctx.handle, self.shard._h, self.cur.h, C.c_void_p(self.stats.data_ptr())))
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
-        check(lib().ppca_em_finalize(self.ctx.handle, self.cur.h, C.c_void_p(self.stats.data_ptr()), self._pref, self.nxt.h))
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            check(lib().ppca_em_accumulate(self.ctx.handle, self.shard._h, self.cur.h, C.c_void_p(self.stats.data_ptr())))
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                dist.all_reduce(self.stats, op=dist.ReduceOp.SUM, group=self.group)
+            check(lib().ppca_em_finalize(self.ctx.handle, self.cur.h, C.c_void_p(self.stats.data_ptr()), self._pref,
+                                         self.nxt.h))
         self.cur, self.nxt = self.nxt, self.cur
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
 
     def llk_of_previous(self) -> float:
         """llk of the model that entered the last step() (synchronises)."""
+        self.stream.synchronize()
         return float(self.stats[stats_len(self.d, self.k) - 8 + 2].item())
 
     def model(self) -> PPCAModel:
+        self.stream.synchronize()
         sig = C.c_double(0.0)
         c = np.empty((self.d, self.k))
         m = np.empty(self.d)
         check(lib().ppca_model_download(self.cur.h, C.byref(sig), ptr(c), ptr(m)))
         return PPCAModel(sig.value, c, m)
+
+    def close(self) -> None:
+        """Detach the library from the torch stream (before the stream object dies)."""
+        self.stream.synchronize()
+        self.ctx.set_stream(None)

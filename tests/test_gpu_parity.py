@@ -309,3 +309,29 @@ def test_generic_pipeline_matches_oracle(P, oracle, n, d, k, mp, block):
     _lib.check(_lib.lib().ppca_covariance_diagonal(ds._ctx.handle, ds._h, m._device(ds._ctx).h, 0, C.byref(_lib_h)))
     dev_diag = P.Dataset._wrap(_lib_h, ds._ctx).numpy()
     assert _rel(dev_diag, diag) < 1e-7
+
+
+def test_two_ranks_on_one_gpu_match_single_rank(P, tmp_path):
+    """The N > 1 path of bench.py (row shards, per-rank pass, all-reduce of the statistics buffer on the
+    launch stream, replicated finalisation) with two ranks sharing this GPU over gloo: the model after
+    a few EM steps equals the single-rank one.  RCCL itself is only exercised by the driver's 8-GPU run."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--samples", "200000", "--no-cpu"]
+    one = str(tmp_path / "one.npz")
+    two = str(tmp_path / "two.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-model", one] + common,
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--dump-model", two] + common,
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(one), np.load(two)
+    assert abs(a["sigma"] - b["sigma"]) < 1e-10 * a["sigma"]
+    assert _rel(b["transform"], a["transform"]) < 1e-9 and _rel(b["mean"], a["mean"]) < 1e-9
+    assert abs(a["llk"] - b["llk"]) < 1e-10 * abs(a["llk"])
