@@ -20,6 +20,7 @@
 // and end with one deterministic per-workgroup partial that reduce_partials sums
 // in fixed order.  No atomics: results are bit-reproducible for a given grid.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ppca_internal.hpp"
 
@@ -51,6 +52,28 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// Wave-wide sum on the DPP data path (VALU speed, no LDS crossbar): quad swaps, half-row and row mirrors,
+// then row_bcast15 / row_bcast31 carry the row totals forward; lane 63 ends up with the total, which is
+// returned as a wave-uniform value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_f64<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 = total
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
@@ -263,16 +286,20 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             double xxr[RPW];
             unsigned long long myw = 0ull;
             int mym = 0;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
+            // Full tiles of full-width rows (the common case) skip the validity ANDs: the finite test alone
+            // decides and its wave mask IS the ballot.
+            const bool full_tile = (tile * B + B <= n) && (d == cfg::DP);
+            auto stage_row = [&](auto full_tag, int r) {
+                constexpr bool FULL = decltype(full_tag)::value;
                 const int ri = wave * RPW + r;
-                const bool row_ok = tile * B + ri < n;
+                const bool row_ok = FULL || (tile * B + ri < n);
                 double xx = 0.0;
                 int m = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double v = xr[r][q];
-                    const bool fin = (int)row_ok & (int)dim_ok[q] & (int)__builtin_isfinite(v);
+                    const bool fin = FULL ? __builtin_isfinite(v)
+                                          : (bool)((int)row_ok & (int)dim_ok[q] & (int)__builtin_isfinite(v));
                     const double xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
                     const unsigned long long bal = __ballot(fin);
                     myw = (lane == 4 * r + q) ? bal : myw;
@@ -282,17 +309,22 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 }
                 xxr[r] = xx;
                 mym = (lane == r) ? m : mym;
+            };
+            if (full_tile) {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) stage_row(std::true_type{}, r);
+            } else {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) stage_row(std::false_type{}, r);
             }
             PPCA_STAMP(4)
-            // independent butterfly reductions, interleaved step by step for ILP
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) xxr[r] += __shfl_xor(xxr[r], o, 64);
-            }
+            // row sums on the DPP path; the (uniform) totals are gathered into the storing lanes
             double myxx = 0.0;
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) myxx = (lane == r) ? xxr[r] : myxx;
+            for (int r = 0; r < RPW; ++r) {
+                const double tot = wave_total(xxr[r]);
+                myxx = (lane == r) ? tot : myxx;
+            }
             PPCA_STAMP(5)
             if (lane < 4 * RPW) Ms[wave * 4 * RPW + lane] = myw;
             if (lane < RPW) {
