@@ -570,9 +570,9 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
         for (int g = 0; g < grid; ++g)
             for (int i = 0; i < 8; ++i) t[i] += h[(size_t)g * 8 + i] / grid;
         const double tiles = (double)((ds->n + FUSED_TILE - 1) / FUSED_TILE) / grid;
-        fprintf(stderr, "[ppca phase cycles/tile] P1 %.0f (stage %.0f reduce %.0f tail+barrier %.0f)  P2 %.0f  P3 %.0f  P4 %.0f  (tiles/WG %.1f)\n",
-                (t[0] + t[4] + t[5]) / tiles, t[4] / tiles, t[5] / tiles, t[0] / tiles, t[1] / tiles, t[2] / tiles,
-                t[3] / tiles, tiles);
+        fprintf(stderr, "[ppca phase cycles/tile] P1 %.0f  P2 %.0f  P3 %.0f  P4 %.0f (prefetch issue %.0f, mfma loop %.0f, barrier %.0f)  (tiles/WG %.1f)\n",
+                (t[0] + t[4] + t[5]) / tiles, t[1] / tiles, t[2] / tiles, (t[3] + t[6] + t[7]) / tiles, t[6] / tiles,
+                t[7] / tiles, t[3] / tiles, tiles);
     }
 #endif
     return PPCA_OK;

@@ -21,6 +21,7 @@
 // in fixed order.  No atomics: results are bit-reproducible for a given grid.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "ppca_internal.hpp"
 
@@ -74,6 +75,24 @@ __device__ __forceinline__ double wave_total(double v) {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// dst[LANE] = sval (wave-uniform value into ONE lane of a VGPR): no compare mask, no select.  The lane
+// select is an immediate: the instruction admits a single SGPR operand (constant-bus limit).
+template <int LANE>
+__device__ __forceinline__ int writelane(int dst, int sval) {
+    // s_nop 1: gfx940+ needs 2 wait states between a VALU that writes an SGPR (the v_cmp ballot) and a
+    // VALU that reads it; hipcc pads its own code but nothing inside an asm statement.
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
+    return dst;
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
@@ -251,17 +270,22 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         dim_ok[q] = 64 * q + lane < d;
         jcl[q] = dim_ok[q] ? 64 * q + lane : d - 1;
     }
+    auto load_row = [&](int64_t tile, int r) {
+        const int64_t row = tile * B + wave * RPW + r;
+        const double *xrow = p.X + (row < n ? row : n - 1) * p.ldx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xr[r][q] = xrow[jcl[q]];  // validity is applied when consumed (P1)
+    };
     auto load_tile = [&](int64_t tile) {
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int64_t row = tile * B + wave * RPW + r;
-            const double *xrow = p.X + (row < n ? row : n - 1) * p.ldx;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xr[r][q] = xrow[jcl[q]];  // validity is applied when consumed (P1)
-        }
+        for (int r = 0; r < RPW; ++r) load_row(tile, r);
     };
-    load_tile(blockIdx.x);
-
+    // Each workgroup walks a CONTIGUOUS run of tiles (consecutive 64 KB pieces of X share pages, unlike a
+    // grid-strided walk that starts every tile 16 MB further on).
+    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+    load_tile(tile_begin);
 #ifdef PPCA_PHASE_TIMING
     long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #define PPCA_STAMP(i)
 #endif
     const int lane_entry = lane;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
         // The lane index is made opaque once per tile: everything derived from it (LDS addresses, shift
         // counts, column maps) is then recomputed per tile -- a few integer ops -- instead of being
         // hoisted out of the loop by LICM and parked in (spilled) registers for the whole kernel.
@@ -284,47 +308,50 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             // will store them -- lane 4r+q keeps mask word q of row r, lane r keeps xx_r / m_r -- so
             // the whole wave does ONE compact store per array instead of many single-address stores.
             double xxr[RPW];
-            unsigned long long myw = 0ull;
+            int myw_lo = 0, myw_hi = 0;
             int mym = 0;
             // Full tiles of full-width rows (the common case) skip the validity ANDs: the finite test alone
-            // decides and its wave mask IS the ballot.
+            // decides and its wave mask IS the ballot; v_writelane drops each (scalar) ballot into the lane
+            // that will store it -- 32 "lane == c" compare masks would overflow the SGPR file.
             const bool full_tile = (tile * B + B <= n) && (d == cfg::DP);
-            auto stage_row = [&](auto full_tag, int r) {
+            auto stage_row = [&](auto full_tag, auto r_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
+                constexpr int r = decltype(r_tag)::value;
                 const int ri = wave * RPW + r;
                 const bool row_ok = FULL || (tile * B + ri < n);
                 double xx = 0.0;
                 int m = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                static_for<4>([&](auto q_tag) {
+                    constexpr int q = decltype(q_tag)::value;
                     const double v = xr[r][q];
                     const bool fin = FULL ? __builtin_isfinite(v)
                                           : (bool)((int)row_ok & (int)dim_ok[q] & (int)__builtin_isfinite(v));
                     const double xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
                     const unsigned long long bal = __ballot(fin);
-                    myw = (lane == 4 * r + q) ? bal : myw;
+                    myw_lo = writelane<4 * r + q>(myw_lo, (int)(unsigned)bal);
+                    myw_hi = writelane<4 * r + q>(myw_hi, (int)(unsigned)(bal >> 32));
                     Xs[ri * XS + 64 * q + lane] = xt;
                     xx += xt * xt;
                     m += __popcll(bal);
-                }
+                });
                 xxr[r] = xx;
-                mym = (lane == r) ? m : mym;
+                mym = writelane<r>(mym, m);
             };
             if (full_tile) {
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) stage_row(std::true_type{}, r);
+                static_for<RPW>([&](auto r_tag) { stage_row(std::true_type{}, r_tag); });
             } else {
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) stage_row(std::false_type{}, r);
+                static_for<RPW>([&](auto r_tag) { stage_row(std::false_type{}, r_tag); });
             }
-            PPCA_STAMP(4)
+            const unsigned long long myw = ((unsigned long long)(unsigned)myw_hi << 32) | (unsigned)myw_lo;
             // row sums on the DPP path; the (uniform) totals are gathered into the storing lanes
-            double myxx = 0.0;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const double tot = wave_total(xxr[r]);
-                myxx = (lane == r) ? tot : myxx;
-            }
+            int xx_lo = 0, xx_hi = 0;
+            static_for<RPW>([&](auto r_tag) {
+                constexpr int r = decltype(r_tag)::value;
+                const long long tb = __double_as_longlong(wave_total(xxr[r]));
+                xx_lo = writelane<r>(xx_lo, (int)tb);
+                xx_hi = writelane<r>(xx_hi, (int)(tb >> 32));
+            });
+            const double myxx = __longlong_as_double(((long long)xx_hi << 32) | (unsigned)xx_lo);
             PPCA_STAMP(5)
             if (lane < 4 * RPW) Ms[wave * 4 * RPW + lane] = myw;
             if (lane < RPW) {
@@ -470,7 +497,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         }
         __syncthreads();
         PPCA_STAMP(1)
-        if constexpr (!EM) load_tile(tile + gridDim.x);  // unconditional: rows are clamped, see load_tile
+        if constexpr (!EM) load_tile(tile + 1);  // unconditional: rows are clamped, see load_tile
         // ------------------------------------------------------------ P3
         // Every wave factors every sample (lane = sample, redundantly, in parallel) and the waves
         // share the independent columns of M^-1; wave 0 also owns z, llk and the scalars.
@@ -541,11 +568,16 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         __syncthreads();
         PPCA_STAMP(2)
         if constexpr (EM) {
-            load_tile(tile + gridDim.x);  // unconditional (clamped rows): no old value stays live across P2/P3
+            // The next tile's rows are requested two rows per k-step, behind that step's MFMAs: a burst of
+            // all 4 RPW loads stalls the wave ~2.9k cycles on the memory queue (a CU drains ~10 B/cycle).
+            PPCA_STAMP(6)
             // -------------------------------------------------------- P4
-            constexpr int UNR = (NW == 4) ? 2 : 4;
-#pragma unroll UNR
+#pragma unroll
             for (int s = 0; s < 8; ++s) {
+                if (2 * s < RPW) {  // two rows per step in the first half: the last request has 4 steps to land
+                    load_row(tile + 1, 2 * s);  // unconditional (clamped rows)
+                    if (2 * s + 1 < RPW) load_row(tile + 1, 2 * s + 1);
+                }
                 const int smp = 4 * s + l4;
                 const unsigned long long mw = Ms[smp * 4 + (DW * wave) / 64];
                 double bw[NTM];
@@ -560,6 +592,10 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     accX[r] = mfma(ax, bw[NTP], accX[r]);
                 }
             }
+#ifdef PPCA_PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: charge the prefetch wait to P4
+#endif
+            PPCA_STAMP(7)
         } else if (p.recon) {
             // output pass: smooth / extrapolate (ppca_model.rs:454-463) or covariance
             // diagonals (:485-508, :542-577); one row per wave iteration, lanes over dims
