@@ -162,12 +162,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------ wave-level SPD tools (runtime k <= 64)
-// Matrix in LDS, row-major with leading dimension LD; lane r owns row r.  The factor overwrites
-// the lower triangle, diagonal slots hold 1/L_pp.  Returns false when a pivot is not positive.
-__device__ bool wave_cholesky(volatile double *Mw, int k, int LD, int lane, double &logdet) {
+// Matrix in LDS, row-major with leading dimension LD; lane r owns row r.  Plain (non-volatile) LDS
+// pointers so the inner loops can be unrolled and their loads batched; lanes exchange data through LDS
+// only at the explicit wave_sync() points (LDS operations of one wave execute in issue order; the fence
+// stops hipcc from moving accesses across the point).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The factor overwrites the lower triangle, diagonal slots hold 1/L_pp.  Returns false when a pivot is
+// not positive.
+__device__ bool wave_cholesky(double *Mw, int k, int LD, int lane, double &logdet) {
     bool ok = true;
     double mant = 1.0;
     int ex = 0;
+    wave_sync();
     for (int p = 0; p < k; ++p) {
         const double piv = Mw[p * LD + p];
         ok = ok && (piv > 0.0) && (piv < 1.0e308);
@@ -176,26 +186,32 @@ __device__ bool wave_cholesky(volatile double *Mw, int k, int LD, int lane, doub
         mant *= frexp(piv, &e);
         ex += e;
         double lrp = 0.0;
+        wave_sync();  // everyone has read the pivot before its slot is overwritten
         if (lane > p && lane < k) {
             lrp = Mw[lane * LD + p] * rinv;
             Mw[lane * LD + p] = lrp;
         }
         if (lane == p) Mw[p * LD + p] = rinv;
+        wave_sync();  // column p is final
+        double *myrow = Mw + (lane < k ? lane : 0) * LD;
+#pragma unroll 8
         for (int c = p + 1; c < k; ++c) {
             const double lcp = Mw[c * LD + p];
-            if (lane >= c && lane < k) Mw[lane * LD + c] -= lrp * lcp;
+            if (lane >= c && lane < k) myrow[c] -= lrp * lcp;
         }
+        wave_sync();  // trailing update visible before the next pivot is read
     }
     logdet = log(mant) + (double)ex * LN_2;
     return ok;
 }
 
 // Solve (L L^T) z = v, lane r holds v_r on entry and z_r on exit; quad = |L^-1 v|^2.
-__device__ double wave_chol_solve(volatile double *Mw, int k, int LD, int lane, double v, double &quad) {
+__device__ double wave_chol_solve(const double *Mw, int k, int LD, int lane, double v, double &quad) {
+    const int lr = lane < k ? lane : 0;
     for (int p = 0; p < k; ++p) {
         const double yp = __shfl(v, p, 64) * Mw[p * LD + p];
         if (lane == p) v = yp;
-        if (lane > p && lane < k) v -= Mw[lane * LD + p] * yp;
+        if (lane > p && lane < k) v -= Mw[lr * LD + p] * yp;
     }
     quad = gwave_sum(lane < k ? v * v : 0.0);
     for (int p = k - 1; p >= 0; --p) {
@@ -206,18 +222,33 @@ __device__ double wave_chol_solve(volatile double *Mw, int k, int LD, int lane, 
     return v;
 }
 
-// Uw[a][c] = (M^-1)_{ac}; lane c owns column c (two triangular solves per column, lanes independent).
-__device__ void wave_chol_inverse(volatile double *Mw, volatile double *Uw, int k, int LD, int lane) {
+// Uw[a][c] = (M^-1)_{ac}; lane c owns column c (two triangular solves per column, lanes independent:
+// Mw is read-only here and each lane touches only its own column of Uw, so no wave_sync is needed).
+__device__ void wave_chol_inverse(const double *Mw, double *Uw, int k, int LD, int lane) {
     const int c = lane < k ? lane : k - 1;
+    double *ucol = Uw + c;
     for (int a = 0; a < k; ++a) {
-        double s = (a == c) ? 1.0 : 0.0;
-        for (int t = 0; t < a; ++t) s -= Mw[a * LD + t] * Uw[t * LD + c];
-        if (lane < k) Uw[a * LD + c] = (a >= c) ? s * Mw[a * LD + a] : 0.0;
+        double s0 = (a == c) ? 1.0 : 0.0, s1 = 0.0;
+        const double *mrow = Mw + a * LD;
+        int t = 0;
+#pragma unroll 4
+        for (; t + 2 <= a; t += 2) {  // two partial sums: shorter dependency chains
+            s0 -= mrow[t] * ucol[t * LD];
+            s1 -= mrow[t + 1] * ucol[(t + 1) * LD];
+        }
+        if (t < a) s0 -= mrow[t] * ucol[t * LD];
+        if (lane < k) ucol[a * LD] = (a >= c) ? (s0 + s1) * mrow[a] : 0.0;
     }
     for (int a = k - 1; a >= 0; --a) {
-        double s = Uw[a * LD + c];
-        for (int t = a + 1; t < k; ++t) s -= Mw[t * LD + a] * Uw[t * LD + c];
-        if (lane < k) Uw[a * LD + c] = s * Mw[a * LD + a];
+        double s0 = ucol[a * LD], s1 = 0.0;
+        int t = a + 1;
+#pragma unroll 4
+        for (; t + 2 <= k; t += 2) {
+            s0 -= Mw[t * LD + a] * ucol[t * LD];
+            s1 -= Mw[(t + 1) * LD + a] * ucol[(t + 1) * LD];
+        }
+        if (t < k) s0 -= Mw[t * LD + a] * ucol[t * LD];
+        if (lane < k) ucol[a * LD] = (s0 + s1) * Mw[a * LD + a];
     }
 }
 
@@ -242,14 +273,15 @@ __global__ __launch_bounds__(128) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = a.k, kp = k * (k + 1) / 2, LD = k | 1;
-    volatile double *Mw = gsm + (size_t)wave * (2 * k * LD + 64);
-    volatile double *Uw = Mw + k * LD;
-    volatile double *zw = Uw + k * LD;
+    double *Mw = gsm + (size_t)wave * (2 * k * LD + 64);
+    double *Uw = Mw + k * LD;
+    double *zw = Uw + k * LD;
     const double s2 = a.model[1], lnsig = a.model[2];
     const int64_t stride = (int64_t)gridDim.x * 2;
     for (int64_t i = (int64_t)blockIdx.x * 2 + wave; i < a.n; i += stride) {
         double *g = a.G + i * kp;
         double *bz = a.Bz + i * (k + 1);
+        wave_sync();  // previous sample's reads of Mw/Uw/zw are done
         for (int e = lane; e < kp; e += 64) {
             int r = 0;
             while ((r + 1) * (r + 2) / 2 <= e) ++r;
@@ -263,6 +295,7 @@ __global__ __launch_bounds__(128) void solve_kernel(SolveArgs a) {
         if (lane < k) zw[lane] = z;
         const double zz = gwave_sum(lane < k ? z * z : 0.0);
         wave_chol_inverse(Mw, Uw, k, LD, lane);
+        wave_sync();  // zw and Uw columns are read across lanes below
         const double tr = gwave_sum(lane < k ? Uw[lane * LD + lane] : 0.0);
         const double wgt = a.w ? a.w[i] : 1.0;
         const double xx = a.xx[i];
@@ -367,10 +400,11 @@ __global__ __launch_bounds__(128) void gen_rowsolve_kernel(const double *stats, 
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kp = k * (k + 1) / 2, LD = k | 1;
-    volatile double *Mw = gsm + (size_t)wave * (k * LD + 64);
+    double *Mw = gsm + (size_t)wave * (k * LD + 64);
     const StatsLayout L(d, k);
     for (int j = blockIdx.x * 2 + wave; j < d; j += gridDim.x * 2) {
         const double *S = stats + L.S + (int64_t)j * kp;
+        wave_sync();
         for (int e = lane; e < kp; e += 64) {
             int r = 0;
             while ((r + 1) * (r + 2) / 2 <= e) ++r;
