@@ -337,6 +337,131 @@ __global__ __launch_bounds__(128) void solve_kernel(SolveArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ register-resident per-sample solve
+// One wave per sample, no LDS: lane r keeps row r of M = G + s2 I (padded to KPAD with an identity block)
+// in registers, lane c keeps column c of M^-1.  Every quantity the lanes share -- pivots, the L_cp of the
+// trailing update, the L_at of the triangular solves, b_a, z_a -- is wave-uniform and is broadcast with
+// v_readlane into a scalar operand of the FMA, so the O(k^3) loops are straight-line register code.
+template <int KPAD>
+__global__ __launch_bounds__(256) void solve_reg_kernel(SolveArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = a.k, kp = k * (k + 1) / 2;
+    const double s2 = a.model[1], lnsig = a.model[2];
+    auto bcast = [&](double v, int src) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < a.n; i += stride) {
+        double *g = a.G + i * kp;
+        double *bz = a.Bz + i * (k + 1);
+        const bool live = lane < k;
+        double row[KPAD];
+        {
+            const double *grow = g + (live ? lane * (lane + 1) / 2 : 0);
+#pragma unroll
+            for (int t = 0; t < KPAD; ++t) {
+                double v = (t == lane) ? 1.0 : 0.0;            // identity padding
+                if (live && t <= lane) v = grow[t] + (t == lane ? s2 : 0.0);
+                row[t] = v;                                      // entries above the diagonal are never read
+            }
+        }
+        const double bv = live ? bz[lane] : 0.0;
+        // Cholesky, right-looking; diagonal slots keep 1 / L_pp
+        double mant = 1.0;
+        int ex = 0;
+#pragma unroll
+        for (int p = 0; p < KPAD; ++p) {
+            const double piv = bcast(row[p], p);
+            const double rinv = 1.0 / sqrt(piv);
+            int e;
+            mant *= frexp(piv, &e);
+            ex += e;
+            row[p] = (lane == p) ? rinv : row[p] * rinv;
+#pragma unroll
+            for (int c = p + 1; c < KPAD; ++c) row[c] -= row[p] * bcast(row[p], c);  // lanes < c touch unused slots
+        }
+        const double logdet = log(mant) + (double)ex * LN_2;
+        // column `lane` of M^-1: L u = e_lane, L^T x = u; L_at is uniform -> scalar operand
+        double u[KPAD];
+#pragma unroll
+        for (int r = 0; r < KPAD; ++r) {
+            double sacc = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int t = 0; t < r; ++t) sacc -= bcast(row[t], r) * u[t];
+            u[r] = sacc * bcast(row[r], r);
+        }
+#pragma unroll
+        for (int r = KPAD - 1; r >= 0; --r) {
+            double sacc = u[r];
+#pragma unroll
+            for (int t = r + 1; t < KPAD; ++t) sacc -= bcast(row[r], t) * u[t];
+            u[r] = sacc * bcast(row[r], r);
+        }
+        // z_c = sum_a (M^-1)_{ac} b_a (symmetry: lane c holds column c), quad = b^T z
+        double z = 0.0, diag = 0.0;
+#pragma unroll
+        for (int r = 0; r < KPAD; ++r) {
+            z += u[r] * bcast(bv, r);
+            diag = (r == lane) ? u[r] : diag;
+        }
+        const double quad = gwave_sum(live ? bv * z : 0.0);
+        const double zz = gwave_sum(live ? z * z : 0.0);
+        const double tr = gwave_sum(live ? diag : 0.0);
+        const double wgt = a.w ? a.w[i] : 1.0;
+        const double xx = a.xx[i];
+        const int m = (int)a.mc[i];
+        const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, k);
+        if (a.em) {
+#pragma unroll
+            for (int r = 0; r < KPAD; ++r) {
+                const double zr = bcast(z, r);
+                if (live && r >= lane && r < k) g[r * (r + 1) / 2 + lane] = wgt * (zr * z + s2 * u[r]);
+            }
+            if (live) bz[lane] = wgt * z;
+            if (lane == 0) {
+                bz[k] = wgt;
+                double *sc = a.sc + i * 4;
+                sc[0] = m > 0 ? wgt * s2 * ((double)k - s2 * tr) : 0.0;
+                sc[1] = m > 0 ? wgt * (xx - quad - s2 * zz) : 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = m > 0 ? 1.0 : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPAD; ++r) {
+                const double sv = s2 * u[r];
+                if (live && r < k) {
+                    if (a.covs) a.covs[(i * k + r) * k + lane] = sv;
+                    if (r >= lane) g[r * (r + 1) / 2 + lane] = sv;  // Sigma packed, for covariance diagonals
+                }
+            }
+            if (live) {
+                bz[lane] = z;  // unweighted state for the reconstruction pass
+                if (a.states) a.states[i * k + lane] = z;
+            }
+            if (lane == 0) {
+                double *sc = a.sc + i * 4;
+                sc[0] = 0.0;
+                sc[1] = 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = 0.0;
+                if (a.llks) a.llks[i] = lk;
+            }
+        }
+    }
+}
+
+static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
+    int grid = (int)std::min<int64_t>((a.n + 3) / 4, (int64_t)n_cu);
+    if (grid < 1) grid = 1;
+    if (a.k <= 16) hipLaunchKernelGGL((solve_reg_kernel<16>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.k <= 32) hipLaunchKernelGGL((solve_reg_kernel<32>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((solve_reg_kernel<64>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // strided column sum of sc[n][4] (+ sum of weights) into scal[8]; one block, deterministic
 __global__ void scal_reduce_kernel(const double *sc, const double *w, int64_t n, double *scal, int accumulate) {
     __shared__ double red[256][5];
@@ -557,10 +682,14 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         a.llks = llks ? llks + r0 : nullptr;
         a.states = states ? states + r0 * k : nullptr;
         a.covs = covs ? covs + r0 * (int64_t)k * k : nullptr;
-        int sgrid = (int)std::min<int64_t>((nc + 1) / 2, (int64_t)n_cu);
-        if (sgrid < 1) sgrid = 1;
-        hipLaunchKernelGGL(solve_kernel, dim3(sgrid), dim3(128), solve_lds(k), s, a);
-        GTRY(hipGetLastError());
+        if (getenv("PPCA_GENERIC_LDS_SOLVE")) {  // the LDS-resident variant, kept for A/B runs
+            int sgrid = (int)std::min<int64_t>((nc + 1) / 2, (int64_t)n_cu);
+            if (sgrid < 1) sgrid = 1;
+            hipLaunchKernelGGL(solve_kernel, dim3(sgrid), dim3(128), solve_lds(k), s, a);
+            GTRY(hipGetLastError());
+        } else {
+            GTRY(launch_solve(a, n_cu, s));
+        }
         double *scal = em ? stats + L.scalars : scal8;
         hipLaunchKernelGGL(scal_reduce_kernel, dim3(1), dim3(256), 0, s, W.sc, wc, nc, scal, (em || r0 > 0) ? 1 : 0);
         GTRY(hipGetLastError());
