@@ -86,6 +86,10 @@ struct GemmArgs {
     double *out1;
     int64_t ld1;
     int accumulate;
+    // split-K: blockIdx.z handles K-range [z * kslice, (z+1) * kslice) and writes a dense M x N partial at
+    // part + z * M * N (then splitk_reduce_kernel adds the partials to the outputs in slice order)
+    int64_t kslice;
+    double *part;
 };
 
 template <int AMODE>
@@ -98,7 +102,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     d4g_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = d4g_t{0, 0, 0, 0};
-    for (int64_t k0 = 0; k0 < g.K; k0 += 16) {
+    const int64_t kbeg = g.part ? (int64_t)blockIdx.z * g.kslice : 0;
+    const int64_t kend = g.part ? ((kbeg + g.kslice < g.K) ? kbeg + g.kslice : g.K) : g.K;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
         // A tile: 64 (M) x 16 (K)
         if (AMODE < 2) {
             const int i = tid >> 2, kk = (tid & 3) * 4;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             for (int u = 0; u < 4; ++u) {
                 const int64_t col = k0 + kk + u;
                 double v = 0.0;
-                if (row < g.M && col < g.K) {
+                if (row < g.M && col < kend) {
                     double x = g.X[row * g.ldx + col];
                     bool fin = __builtin_isfinite(x);
                     v = (AMODE == 0) ? (fin ? 1.0 : 0.0) : (fin ? x - g.mean[col] : 0.0);
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             for (int u = 0; u < 4; ++u) {
                 const int64_t dim = m0 + jj + u;
                 double v = 0.0;
-                if (srow < g.K && dim < g.M) {
+                if (srow < kend && dim < g.M) {
                     double x = g.X[srow * g.ldx + dim];
                     bool fin = __builtin_isfinite(x);
                     v = (AMODE == 2) ? (fin ? 1.0 : 0.0) : (fin ? x - g.mean[dim] : 0.0);
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t col = n0 + cc + u;
-                Bs[kk][cc + u] = (kr < g.K && col < g.N) ? g.B[kr * g.ldb + col] : 0.0;
+                Bs[kk][cc + u] = (kr < kend && col < g.N) ? g.B[kr * g.ldb + col] : 0.0;
             }
         }
         __syncthreads();
@@ -155,8 +161,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int r = 0; r < 4; ++r) {
             const int64_t row = m0 + 16 * wave + l4 + 4 * r, col = n0 + 16 * t + l15;
             if (row < g.M && col < g.N) {
-                double *dst = (col < g.ncols0) ? g.out0 + row * g.ld0 + col : g.out1 + row * g.ld1 + (col - g.ncols0);
-                *dst = g.accumulate ? *dst + acc[t][r] : acc[t][r];
+                if (g.part) {
+                    g.part[((int64_t)blockIdx.z * g.M + row) * g.N + col] = acc[t][r];
+                } else {
+                    double *dst = (col < g.ncols0) ? g.out0 + row * g.ld0 + col : g.out1 + row * g.ld1 + (col - g.ncols0);
+                    *dst = g.accumulate ? *dst + acc[t][r] : acc[t][r];
+                }
             }
         }
 }
@@ -590,15 +600,21 @@ static int64_t gen_chunk(int k) {
     return c;
 }
 
+// split-K scratch: up to 4 dense (d x k') partials (and >= 16 of the (d x (k+1)) ones)
+static int64_t gen_part_doubles(int d, int k) {
+    const int64_t kp = (int64_t)k * (k + 1) / 2;
+    return std::max<int64_t>(4 * (int64_t)d * kp, 64 * (int64_t)d * (k + 1));
+}
+
 size_t generic_workspace_bytes(int d, int k, int64_t n) {
     const int64_t kp = (int64_t)k * (k + 1) / 2;
     const int64_t c = std::min<int64_t>(gen_chunk(k), std::max<int64_t>(n, 1));
-    return sizeof(double) * (size_t)((int64_t)d * kp + c * (kp + (k + 1) + 2 + 4) + 64);
+    return sizeof(double) * (size_t)((int64_t)d * kp + c * (kp + (k + 1) + 2 + 4) + 64 + gen_part_doubles(d, k));
 }
 
 struct GenWs {
-    double *Q, *G, *Bz, *xx, *mc, *sc;
-    int64_t chunk;
+    double *Q, *G, *Bz, *xx, *mc, *sc, *part;
+    int64_t chunk, part_cap;
 };
 static GenWs carve(void *ws, int d, int k, int64_t n) {
     const int64_t kp = (int64_t)k * (k + 1) / 2;
@@ -610,15 +626,52 @@ static GenWs carve(void *ws, int d, int k, int64_t n) {
     w.Bz = p; p += w.chunk * (k + 1);
     w.xx = p; p += w.chunk;
     w.mc = p; p += w.chunk;
-    w.sc = p;
+    w.sc = p; p += 4 * w.chunk;
+    w.part = p;
+    w.part_cap = gen_part_doubles(d, k);
     return w;
 }
 
+// out(r, c) (+)= sum over slices, in slice order (deterministic)
+__global__ void splitk_reduce_kernel(GemmArgs g, int nslices) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.M * g.N) return;
+    const int64_t row = idx / g.N, col = idx - row * g.N;
+    double sacc = 0.0;
+    for (int z = 0; z < nslices; ++z) sacc += g.part[(int64_t)z * g.M * g.N + idx];
+    double *dst = (col < g.ncols0) ? g.out0 + row * g.ld0 + col : g.out1 + row * g.ld1 + (col - g.ncols0);
+    *dst = g.accumulate ? *dst + sacc : sacc;
+}
+
+// part_ws / part_cap: split-K scratch (doubles); a product whose tile grid would not fill the chip ~4x over
+// is cut along K into enough slices to do so.
 template <int AMODE>
-static hipError_t launch_gemm(const GemmArgs &g, hipStream_t s) {
+static hipError_t launch_gemm(GemmArgs g, hipStream_t s, int n_cu = 256, double *part_ws = nullptr,
+                              int64_t part_cap = 0) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64));
+    const int64_t tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64);
+    int64_t ksplit = 1;
+    if (part_ws && tiles < 4 * (int64_t)n_cu) {
+        ksplit = (8 * (int64_t)n_cu + tiles - 1) / tiles;
+        ksplit = std::min<int64_t>(ksplit, std::max<int64_t>(1, g.K / 256));
+        ksplit = std::min<int64_t>(ksplit, part_cap / std::max<int64_t>(1, g.M * g.N));
+        if (ksplit > 64) ksplit = 64;
+    }
+    if (ksplit <= 1) {
+        g.part = nullptr;
+        dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64));
+        hipLaunchKernelGGL((gemm_kernel<AMODE>), grid, dim3(256), 0, s, g);
+        return hipGetLastError();
+    }
+    g.part = part_ws;
+    g.kslice = ((g.K + ksplit - 1) / ksplit + 15) / 16 * 16;
+    const int nsl = (int)((g.K + g.kslice - 1) / g.kslice);
+    dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)nsl);
     hipLaunchKernelGGL((gemm_kernel<AMODE>), grid, dim3(256), 0, s, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t tot = g.M * g.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, g, nsl);
     return hipGetLastError();
 }
 
@@ -697,14 +750,14 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
             // S += Mask^T . wP
             g.B = W.G; g.ldb = kp; g.M = d; g.N = kp; g.K = nc;
             g.out0 = stats + L.S; g.ld0 = kp; g.ncols0 = kp; g.accumulate = 1;
-            GTRY(launch_gemm<2>(g, s));
+            GTRY(launch_gemm<2>(g, s, n_cu, W.part, W.part_cap));
             // [U | totals] += Mask^T . [wz | w]
             g.B = W.Bz; g.ldb = k + 1; g.N = k + 1;
             g.out0 = stats + L.U; g.ld0 = k; g.ncols0 = k; g.out1 = stats + L.totals; g.ld1 = 1;
-            GTRY(launch_gemm<2>(g, s));
+            GTRY(launch_gemm<2>(g, s, n_cu, W.part, W.part_cap));
             // [cross | sumx] += X~^T . [wz | w]
             g.out0 = stats + L.cross; g.out1 = stats + L.sumx;
-            GTRY(launch_gemm<3>(g, s));
+            GTRY(launch_gemm<3>(g, s, n_cu, W.part, W.part_cap));
         } else if (recon) {
             const int64_t tot = nc * d;
             hipLaunchKernelGGL(recon_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, ldx, nc, d, k,
