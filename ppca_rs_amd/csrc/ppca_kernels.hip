@@ -45,8 +45,13 @@ struct Cfg {
     static constexpr int OFF_G = OFF_C + DP * CS;
     static constexpr int OFF_W = OFF_G + 2 * B * GS;
     static constexpr int OFF_M = OFF_W + B * WS;  // mask words, B x 4 u64
-    static constexpr int OFF_S = OFF_M + B * 4;   // xx[B] doubles, then m[B] ints
-    static constexpr int LDS_DOUBLES = OFF_S + 2 * B;
+    static constexpr int OFF_S = OFF_M + 2 * B * 4;  // (two parities: the next tile is staged behind P4)
+                                                     // then xx[B] doubles, m[B] ints
+    // running per-solver-lane scalars (kept out of registers: at this pressure hipcc parks loop-carried
+    // once-per-tile values in scratch and reloads them with an exposed vmcnt(0)):
+    // sq[NW <= 8 waves][B] | dev[B] | llk[B] | sumw[B] | nonempty[B] | det mantissa[B] | det exponent[B]
+    static constexpr int OFF_L = OFF_S + 2 * B;
+    static constexpr int LDS_DOUBLES = OFF_L + 14 * B;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -83,7 +88,7 @@ template <int LANE>
 __device__ __forceinline__ int writelane(int dst, int sval) {
     // s_nop 1: gfx940+ needs 2 wait states between a VALU that writes an SGPR (the v_cmp ballot) and a
     // VALU that reads it; hipcc pads its own code but nothing inside an asm statement.
-    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
     return dst;
 }
 template <class F, int... I>
@@ -256,7 +261,14 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             accX[r] = d4_t{0, 0, 0, 0};
         }
     }
-    double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;
+    // unweighted EM pass: sum_i ln det M_i = ln prod_i det M_i, so each solver lane keeps a running
+    // (mantissa, exponent) product and takes ONE logarithm at the end of the kernel (a per-tile fp64 log
+    // cost 2.2k of ~35k cycles per tile: its constants live in scratch at this register pressure)
+    double *scl = sm + cfg::OFF_L;
+    constexpr int L_DEV = NW * B, L_LLK = (NW + 1) * B, L_W = (NW + 2) * B, L_NE = (NW + 3) * B, L_PM = (NW + 4) * B,
+                  L_PX = (NW + 5) * B;
+    for (int idx = tid; idx < (NW + 6) * B; idx += THREADS) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
+    const double inv_s2 = 1.0 / s2;
 
     const int64_t ntiles = (n + B - 1) / B;
     double xr[RPW][4];
@@ -287,12 +299,87 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
     load_tile(tile_begin);
 #ifdef PPCA_PHASE_TIMING
-    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
 #define PPCA_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
 #else
 #define PPCA_STAMP(i)
 #endif
+    // ---- P1 as three pieces, so that the EM pass can run it for tile t+1 inside tile t's P4.
+    // Wave-uniform results (mask words, popcounts, row sums) are gathered into the lane that will store
+    // them -- lane 4r+q keeps mask word q of row r, lane r keeps xx_r / m_r (v_writelane drops each scalar
+    // into its lane: 32 "lane == c" compare masks would overflow the SGPR file) -- so the whole wave does
+    // ONE compact store per array.
+    int st_wlo = 0, st_whi = 0, st_m = 0, st_xlo = 0, st_xhi = 0;
+    auto stage_begin = [&]() { st_wlo = st_whi = st_m = st_xlo = st_xhi = 0; };
+    // One row = 16 small pieces (each well under the 64 cycles of one fp64 MFMA) so that P4 can drop one
+    // piece behind each of its MFMAs: 2q = classify + centre quarter q, 2q+1 = file its ballot / x~ / sums,
+    // 8 = popcount, 9..14 = the six DPP steps of the row sum, 15 = row sum into its lane.
+    constexpr int STAGE_PIECES = 16;
+    double pc_xt = 0.0, pc_xx = 0.0;
+    unsigned long long pc_bal = 0ull;
+    int pc_m = 0;
+    auto stage_piece = [&](int64_t t, int lane, auto r_tag, auto p_tag) {
+        constexpr int r = decltype(r_tag)::value, P = decltype(p_tag)::value;
+        const int ri = wave * RPW + r;
+        if constexpr (P < 8 && (P & 1) == 0) {
+            constexpr int q = P / 2;
+            if constexpr (q == 0) {
+                pc_xx = 0.0;
+                pc_m = 0;
+            }
+            const bool row_ok = t * B + ri < n;  // wave-uniform
+            const double v = xr[r][q];
+            const bool fin = (bool)((int)row_ok & (int)dim_ok[q] & (int)__builtin_isfinite(v));
+            pc_xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
+            pc_bal = __ballot(fin);
+        } else if constexpr (P < 8) {
+            constexpr int q = P / 2;
+            st_wlo = writelane<4 * r + q>(st_wlo, (int)(unsigned)pc_bal);
+            st_whi = writelane<4 * r + q>(st_whi, (int)(unsigned)(pc_bal >> 32));
+            Xs[ri * XS + 64 * q + lane] = pc_xt;
+            pc_xx += pc_xt * pc_xt;
+            pc_m += __popcll(pc_bal);
+        } else if constexpr (P == 8) {
+            st_m = writelane<r>(st_m, pc_m);
+        } else if constexpr (P == 9) {
+            pc_xx += dpp_f64<0xB1, 0xF>(pc_xx);   // quad_perm [1,0,3,2]
+        } else if constexpr (P == 10) {
+            pc_xx += dpp_f64<0x4E, 0xF>(pc_xx);   // quad_perm [2,3,0,1]
+        } else if constexpr (P == 11) {
+            pc_xx += dpp_f64<0x141, 0xF>(pc_xx);  // row_half_mirror
+        } else if constexpr (P == 12) {
+            pc_xx += dpp_f64<0x140, 0xF>(pc_xx);  // row_mirror
+        } else if constexpr (P == 13) {
+            pc_xx += dpp_f64<0x142, 0xA>(pc_xx);  // row_bcast15
+        } else if constexpr (P == 14) {
+            pc_xx += dpp_f64<0x143, 0xC>(pc_xx);  // row_bcast31: lane 63 = total
+        } else if constexpr (P == 15) {
+            const long long tb = __double_as_longlong(pc_xx);
+            st_xlo = writelane<r>(st_xlo, __builtin_amdgcn_readlane((int)tb, 63));
+            st_xhi = writelane<r>(st_xhi, __builtin_amdgcn_readlane((int)(tb >> 32), 63));
+        }
+    };
+    auto stage_row = [&](int64_t t, int lane, auto r_tag) {
+        static_for<STAGE_PIECES>([&](auto p_tag) { stage_piece(t, lane, r_tag, p_tag); });
+    };
+    auto stage_end = [&](int lane, int par) {
+        const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
+        const double myxx = __longlong_as_double(((long long)st_xhi << 32) | (unsigned)st_xlo);
+        if (lane < 4 * RPW) Ms[par * 4 * B + wave * 4 * RPW + lane] = myw;
+        if (lane < RPW) {
+            xxs[wave * RPW + lane] = myxx;
+            mcnt[wave * RPW + lane] = st_m;
+        }
+    };
+    if constexpr (EM) {
+        if (tile_begin < tile_end) {
+            stage_begin();
+            static_for<RPW>([&](auto r_tag) { stage_row(tile_begin, lane, r_tag); });
+            stage_end(lane, 0);
+        }
+        __syncthreads();
+    }
     const int lane_entry = lane;
     for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
         // The lane index is made opaque once per tile: everything derived from it (LDS addresses, shift
@@ -303,82 +390,40 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         const int l15 = lane & 15, l4 = lane >> 4;
         const int colb = (l15 < K) ? l15 : K;
         // ------------------------------------------------------------ P1
-        {
-            // Wave-uniform results (mask words, popcounts, row sums) are gathered into the lane that
-            // will store them -- lane 4r+q keeps mask word q of row r, lane r keeps xx_r / m_r -- so
-            // the whole wave does ONE compact store per array instead of many single-address stores.
-            double xxr[RPW];
-            int myw_lo = 0, myw_hi = 0;
-            int mym = 0;
-            // Full tiles of full-width rows (the common case) skip the validity ANDs: the finite test alone
-            // decides and its wave mask IS the ballot; v_writelane drops each (scalar) ballot into the lane
-            // that will store it -- 32 "lane == c" compare masks would overflow the SGPR file.
-            const bool full_tile = (tile * B + B <= n) && (d == cfg::DP);
-            auto stage_row = [&](auto full_tag, auto r_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
-                constexpr int r = decltype(r_tag)::value;
-                const int ri = wave * RPW + r;
-                const bool row_ok = FULL || (tile * B + ri < n);
-                double xx = 0.0;
-                int m = 0;
-                static_for<4>([&](auto q_tag) {
-                    constexpr int q = decltype(q_tag)::value;
-                    const double v = xr[r][q];
-                    const bool fin = FULL ? __builtin_isfinite(v)
-                                          : (bool)((int)row_ok & (int)dim_ok[q] & (int)__builtin_isfinite(v));
-                    const double xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
-                    const unsigned long long bal = __ballot(fin);
-                    myw_lo = writelane<4 * r + q>(myw_lo, (int)(unsigned)bal);
-                    myw_hi = writelane<4 * r + q>(myw_hi, (int)(unsigned)(bal >> 32));
-                    Xs[ri * XS + 64 * q + lane] = xt;
-                    xx += xt * xt;
-                    m += __popcll(bal);
-                });
-                xxr[r] = xx;
-                mym = writelane<r>(mym, m);
-            };
-            if (full_tile) {
-                static_for<RPW>([&](auto r_tag) { stage_row(std::true_type{}, r_tag); });
-            } else {
-                static_for<RPW>([&](auto r_tag) { stage_row(std::false_type{}, r_tag); });
-            }
-            const unsigned long long myw = ((unsigned long long)(unsigned)myw_hi << 32) | (unsigned)myw_lo;
-            // row sums on the DPP path; the (uniform) totals are gathered into the storing lanes
-            int xx_lo = 0, xx_hi = 0;
-            static_for<RPW>([&](auto r_tag) {
-                constexpr int r = decltype(r_tag)::value;
-                const long long tb = __double_as_longlong(wave_total(xxr[r]));
-                xx_lo = writelane<r>(xx_lo, (int)tb);
-                xx_hi = writelane<r>(xx_hi, (int)(tb >> 32));
-            });
-            const double myxx = __longlong_as_double(((long long)xx_hi << 32) | (unsigned)xx_lo);
+        // EM: the tile was staged behind the previous tile's P4 (or before the loop for the first one)
+        if constexpr (!EM) {
+            stage_begin();
+            static_for<RPW>([&](auto r_tag) { stage_row(tile, lane, r_tag); });
             PPCA_STAMP(5)
-            if (lane < 4 * RPW) Ms[wave * 4 * RPW + lane] = myw;
-            if (lane < RPW) {
-                xxs[wave * RPW + lane] = myxx;
-                mcnt[wave * RPW + lane] = mym;
-            }
+            stage_end(lane, 0);
+            __syncthreads();
         }
-        __syncthreads();
+        const unsigned long long *Msc = Ms + (EM ? (int)((tile - tile_begin) & 1) * 4 * B : 0);
         PPCA_STAMP(0)
         // ------------------------------------------------------------ P2
         {
             // int8 Gram: the slice table of this wave's column tile (QS x 4 fragments of 16 B per lane,
-            // L2-resident) streams through registers in three digit groups, high to low: {7,6} and
-            // {5,4,3} are requested now and land behind the fp64 b = X~ C loop, {2,1,0} is requested
-            // while the first group is contracted.
+            // L2-resident) streams through registers in four digit pairs, high to low: {7,6} and {5,4} are
+            // requested now and land behind the fp64 b = X~ C loop; {3,2} and {1,0} reuse their registers as
+            // soon as a pair has been contracted.  (Three-digit groups kept 80 registers of fragments in
+            // flight across the b loop: hipcc spilled three of them to scratch with a vmcnt(0) each.)
             static_assert(!GI8 || QS == 8, "digit grouping below assumes 8 slices");
             // buffer loads: one scalar resource for the table, a scalar offset per fragment and ONE lane
             // offset register -- no per-load vector addresses for hipcc to keep alive (and spill)
             const __amdgpu_buffer_rsrc_t qrsrc =
                 __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
+            // (the wave's table base is made opaque per tile: 32 loop-invariant scalar offsets would be
+            // hoisted, overflow the SGPR file and come back through v_readlane + s_nop 4 each)
+            int qbase = wave * QS * 4 * 1024;
+            asm volatile("" : "+s"(qbase));
             auto ldq = [&](int sl, int kc) {
                 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane * 16, ((wave * QS + sl) * 4 + kc) * 1024, 0);
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane * 16, qbase + (sl * 4 + kc) * 1024, 0);
                 return i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
             };
-            i4_t qbA[GI8 ? 2 : 1][4], qbB[GI8 ? 3 : 1][4], qbC[GI8 ? 3 : 1][4];
+            i4_t qbA[2][4], qbB[2][4];
             const bool gram_wave = GI8 && wave < NTP;
+            double qs = 0.0;
             if constexpr (GI8) {
                 if (gram_wave) {
 #pragma unroll
@@ -386,16 +431,17 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #pragma unroll
                         for (int kc = 0; kc < 4; ++kc) qbA[u][kc] = ldq(6 + u, kc);
 #pragma unroll
-                    for (int u = 0; u < 3; ++u)
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int kc = 0; kc < 4; ++kc) qbB[u][kc] = ldq(3 + u, kc);
+                        for (int kc = 0; kc < 4; ++kc) qbB[u][kc] = ldq(4 + u, kc);
+                    qs = p.qscale[16 * wave + l15];
                 }
             }
             const int rt = wave & 1, kq = wave >> 1;
             const int si = 16 * rt + l15;
             unsigned long long mw[WPS];
 #pragma unroll
-            for (int i = 0; i < WPS; ++i) mw[i] = Ms[si * 4 + WPS * kq + i];
+            for (int i = 0; i < WPS; ++i) mw[i] = Msc[si * 4 + WPS * kq + i];
             d4_t acc[NTM];
 #pragma unroll
             for (int t = 0; t < NTM; ++t) acc[t] = d4_t{0, 0, 0, 0};
@@ -430,21 +476,20 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     for (int rt2 = 0; rt2 < 2; ++rt2)
 #pragma unroll
                         for (int kc = 0; kc < 4; ++kc) {
-                            const unsigned bits = (unsigned)(Ms[(16 * rt2 + l15) * 4 + kc] >> (16 * l4)) & 0xFFFFu;
+                            const unsigned bits = (unsigned)(Msc[(16 * rt2 + l15) * 4 + kc] >> (16 * l4)) & 0xFFFFu;
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
                                 af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
                         }
-                    // one digit group: contract, then fold the (exact) integer digit sums -- |sum| <= 2^14,
-                    // so up to three digits fit one i32 -- into the running fp64 value, Horner in 128^3
+                    // one digit pair: contract, then fold the (exact) integer digit sums -- |sum| <= 2^14, so
+                    // two digits fit one i32 with room to spare -- into the running fp64 value, Horner in 128^2
                     double v[2][4];
-                    auto group = [&](const i4_t(*qb)[4], int cnt, bool first) {
+                    auto group = [&](const i4_t(*qb)[4], bool first) {
 #pragma unroll
                         for (int rt2 = 0; rt2 < 2; ++rt2) {
-                            i4_t ia[3];
+                            i4_t ia[2];
 #pragma unroll
-                            for (int u = 0; u < 3; ++u) {
-                                if (u >= cnt) continue;
+                            for (int u = 0; u < 2; ++u) {
                                 ia[u] = i4_t{0, 0, 0, 0};
 #pragma unroll
                                 for (int kc = 0; kc < 4; ++kc)
@@ -452,22 +497,23 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                             }
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                int part = 0;
-#pragma unroll
-                                for (int u = 2; u >= 0; --u)
-                                    if (u < cnt) part = part * 128 + ia[u][r];
-                                v[rt2][r] = first ? (double)part : v[rt2][r] * 2097152.0 + (double)part;
+                                const int part = ia[1][r] * 128 + ia[0][r];
+                                v[rt2][r] = first ? (double)part : v[rt2][r] * 16384.0 + (double)part;
                             }
                         }
                     };
-                    group(qbA, 2, true);
+                    group(qbA, true);
 #pragma unroll
-                    for (int u = 0; u < 3; ++u)
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int kc = 0; kc < 4; ++kc) qbC[u][kc] = ldq(u, kc);
-                    group(qbB, 3, false);
-                    group(qbC, 3, false);
-                    const double qs = p.qscale[16 * wave + l15];
+                        for (int kc = 0; kc < 4; ++kc) qbA[u][kc] = ldq(2 + u, kc);
+                    group(qbB, false);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) qbB[u][kc] = ldq(u, kc);
+                    group(qbA, false);
+                    group(qbB, false);
 #pragma unroll
                     for (int rt2 = 0; rt2 < 2; ++rt2)
 #pragma unroll
@@ -509,10 +555,16 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             const double wgt = (row < n) ? (p.w ? p.w[row] : 1.0) : 0.0;
             const int m = mcnt[i];
             double *wrow = Ws + i * WS;
+            double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;  // this tile's terms
+            const double sq_run = scl[wave * B + i];
             Posterior<K> post;
-            const double logdet = post.factor([&](int e) { return GI8 ? g0[e] : g0[e] + g1[e]; }, s2);
+            double pm;
+            int pe;
+            post.factor([&](int e) { return GI8 ? g0[e] : g0[e] + g1[e]; }, s2, pm, pe);
+            PPCA_STAMP(8)
             double z[K], quad, zz;
             post.solve([&](int a) { return g0[16 * NTP + a] + g1[16 * NTP + a]; }, z, quad, zz);
+            PPCA_STAMP(9)
             double trpart = 0.0;
 #pragma unroll
             for (int c = 0; c < K; ++c) {
@@ -532,6 +584,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     });
                 }
             }
+            PPCA_STAMP(10)
             if constexpr (EM) {
                 // tr(C_o Sigma C_o^T) = <Sigma, G> = s2 (K - s2 tr M^-1)  (:345); each wave carries the
                 // share of its columns.  All-masked samples are filtered out of the noise sums (:333).
@@ -557,41 +610,90 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                         for (int a = 0; a < K; ++a) p.states[row * K + a] = z[a];
                     }
                 }
-                const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, K);
-                sc_llk += wgt * lk;
-                sc_w += wgt;
-                if constexpr (!EM) {
+                if constexpr (EM) {
+                    const double lk0 = sample_llk_nolog(xx, quad, inv_s2, lnsig, m, K);
+                    if (p.w) {
+                        sc_llk += wgt * (m > 0 ? lk0 - 0.5 * Posterior<K>::logdet(pm, pe) : 0.0);
+                    } else {
+                        const bool use = m > 0 && row < n;  // wgt is 1 for real rows
+                        sc_llk += use ? lk0 : 0.0;
+                        int e;
+                        scl[L_PM + i] = frexp(scl[L_PM + i] * (use ? pm : 1.0), &e);
+                        scl[L_PX + i] += (double)(e + (use ? pe : 0));
+                    }
+                    sc_w += wgt;
+                } else {
+                    const double lk = sample_llk(xx, quad, Posterior<K>::logdet(pm, pe), s2, lnsig, m, K);
+                    sc_llk += wgt * lk;
+                    sc_w += wgt;
                     if (p.llks && row < n) p.llks[row] = lk;
                 }
+                scl[L_DEV + i] += sc_dev;
+                scl[L_LLK + i] += sc_llk;
+                scl[L_W + i] += sc_w;
+                scl[L_NE + i] += sc_ne;
             }
+            if constexpr (EM) scl[wave * B + i] = sq_run + sc_sq;
         }
+        PPCA_STAMP(11)
         __syncthreads();
         PPCA_STAMP(2)
         if constexpr (EM) {
-            // The next tile's rows are requested two rows per k-step, behind that step's MFMAs: a burst of
-            // all 4 RPW loads stalls the wave ~2.9k cycles on the memory queue (a CU drains ~10 B/cycle).
-            PPCA_STAMP(6)
             // -------------------------------------------------------- P4
+            // (a) cross/sumx += X~^T [wz | w]: the only reader of the x~ tile; the next tile's rows are
+            //     requested one per k-step behind these MFMAs (a burst of all of them stalls the wave
+            //     ~2.9k cycles on the memory queue: a CU drains ~10 B/cycle)
+            PPCA_STAMP(6)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                if (2 * s < RPW) {  // two rows per step in the first half: the last request has 4 steps to land
-                    load_row(tile + 1, 2 * s);  // unconditional (clamped rows)
-                    if (2 * s + 1 < RPW) load_row(tile + 1, 2 * s + 1);
-                }
+                if (s < RPW) load_row(tile + 1, s);  // unconditional (clamped rows)
                 const int smp = 4 * s + l4;
-                const unsigned long long mw = Ms[smp * 4 + (DW * wave) / 64];
-                double bw[NTM];
+                const double bz = Ws[smp * WS + 16 * NTP + l15];
 #pragma unroll
-                for (int t = 0; t < NTM; ++t) bw[t] = Ws[smp * WS + 16 * t + l15];
-#pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    const double am = ((mw >> (((DW * wave) & 63) + 16 * r + l15)) & 1ull) ? 1.0 : 0.0;
-                    const double ax = Xs[smp * XS + DW * wave + 16 * r + l15];
-#pragma unroll
-                    for (int t = 0; t < NTM; ++t) accM[r][t] = mfma(am, bw[t], accM[r][t]);
-                    accX[r] = mfma(ax, bw[NTP], accX[r]);
-                }
+                for (int r = 0; r < RT; ++r)
+                    accX[r] = mfma(Xs[smp * XS + DW * wave + 16 * r + l15], bz, accX[r]);
             }
+            __syncthreads();  // the x~ tile is free
+            PPCA_STAMP(4)
+            // (b) S/U/totals += Mask^T [wP | wz | w], with the staging (P1) of the next tile's rows between the MFMAs
+            stage_begin();
+            // One staging piece follows each MFMA.  Measured (tools/ubench_shadow.hip): v_mfma_f64 holds the
+            // SIMD's VALU port for its 64 cycles -- no VALU instruction of this wave overlaps it, only LDS,
+            // SALU and memory instructions do -- so this interleave hides the staging's LDS writes and the
+            // row-load latency, not its ALU work.  The B operands of step s+1 are read from LDS during step s.
+            unsigned long long mwc = Msc[l4 * 4 + (DW * wave) / 64];
+            double bwc[NTM];
+#pragma unroll
+            for (int t = 0; t < NTM; ++t) bwc[t] = Ws[l4 * WS + 16 * t + l15];
+            static_for<8>([&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                unsigned long long mwn = 0ull;
+                double bwn[NTM];
+                constexpr int SLOTS = RT * NTM;
+                static_for<SLOTS>([&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value, r = i / NTM, t = i % NTM;
+                    const double am = ((mwc >> (((DW * wave) & 63) + 16 * r + l15)) & 1ull) ? 1.0 : 0.0;
+                    accM[r][t] = mfma(am, bwc[t], accM[r][t]);
+                    if constexpr (s < RPW) {  // the row's 16 pieces spread evenly over the step's MFMAs
+                        constexpr int P0 = i * STAGE_PIECES / SLOTS, P1 = (i + 1) * STAGE_PIECES / SLOTS;
+                        static_for<P1 - P0>([&](auto o_tag) {
+                            stage_piece(tile + 1, lane, s_tag, std::integral_constant<int, P0 + decltype(o_tag)::value>{});
+                        });
+                    }
+                    if constexpr (i == SLOTS * 3 / 4 && s + 1 < 8) {
+                        const int smp = 4 * (s + 1) + l4;
+                        mwn = Msc[smp * 4 + (DW * wave) / 64];
+#pragma unroll
+                        for (int tt = 0; tt < NTM; ++tt) bwn[tt] = Ws[smp * WS + 16 * tt + l15];
+                    }
+                });
+                if constexpr (s + 1 < 8) {
+                    mwc = mwn;
+#pragma unroll
+                    for (int t = 0; t < NTM; ++t) bwc[t] = bwn[t];
+                }
+            });
+            stage_end(lane, (int)((tile + 1 - tile_begin) & 1));
 #ifdef PPCA_PHASE_TIMING
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: charge the prefetch wait to P4
 #endif
@@ -607,7 +709,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 for (int q = 0; q < 4; ++q) {
                     const int j = 64 * q + lane;
                     if (j >= d) continue;
-                    const bool obs = (Ms[ri * 4 + q] >> lane) & 1ull;
+                    const bool obs = (Msc[ri * 4 + q] >> lane) & 1ull;
                     const double *cj = Cs + j * CS;
                     double out;
                     if (p.recon_mode <= 1) {
@@ -636,13 +738,13 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     }
 #ifdef PPCA_PHASE_TIMING
     if (p.dbg && tid == 0)
-        for (int i = 0; i < 8; ++i) p.dbg[(int64_t)blockIdx.x * 8 + i] = (double)tph[i];
+        for (int i = 0; i < 12; ++i) p.dbg[(int64_t)blockIdx.x * 12 + i] = (double)tph[i];
 #endif
 
     // ------------------------------------------------------------ epilogue
     // scalars: deterministic reduction over the 32 solver lanes of each wave, then over the waves
     {
-        const double sq_w = wave_sum(lane < B ? sc_sq : 0.0);
+        const double sq_w = wave_sum(lane < B ? scl[wave * B + lane] : 0.0);
         if (lane == 0) xxs[wave] = sq_w;  // xxs is free after the last tile
     }
     __syncthreads();
@@ -650,8 +752,11 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         double v0 = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v0 += xxs[w];
-        double v1 = wave_sum(lane < B ? sc_dev : 0.0), v2 = wave_sum(lane < B ? sc_llk : 0.0),
-               v3 = wave_sum(lane < B ? sc_w : 0.0), v4 = wave_sum(lane < B ? sc_ne : 0.0);
+        const int li = lane < B ? lane : 0;
+        double sc_llk = scl[L_LLK + li];
+        if constexpr (EM) sc_llk -= 0.5 * (log(scl[L_PM + li]) + scl[L_PX + li] * LN_2);
+        double v1 = wave_sum(lane < B ? scl[L_DEV + li] : 0.0), v2 = wave_sum(lane < B ? sc_llk : 0.0),
+               v3 = wave_sum(lane < B ? scl[L_W + li] : 0.0), v4 = wave_sum(lane < B ? scl[L_NE + li] : 0.0);
         if (lane == 0) {
             double *sc;
             if constexpr (EM) {
@@ -952,6 +1057,14 @@ static int em_waves() {
     return nw;
 }
 
+#ifdef PPCA_DEV_K10
+// kernel-tuning builds (tools/devbuild.py): only the k = 10 int8-Gram variants are instantiated
+#define PPCA_DISPATCH_K(k, EXPR)                         \
+    switch (k) {                                         \
+        case 10: { constexpr int KK = 10; EXPR; } break; \
+        default: return hipErrorInvalidValue;            \
+    }
+#else
 #define PPCA_DISPATCH_K(k, EXPR)                         \
     switch (k) {                                         \
         case 1: { constexpr int KK = 1; EXPR; } break;   \
@@ -966,8 +1079,12 @@ static int em_waves() {
         case 10: { constexpr int KK = 10; EXPR; } break; \
         default: return hipErrorInvalidValue;            \
     }
+#endif
 
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
+#ifdef PPCA_DEV_K10
+    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4, true>(grid, a, s)));
+#else
     if (em_waves() == 8) {
         PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 8, false>(grid, a, s)));
     } else if (gram_i8()) {
@@ -975,14 +1092,19 @@ hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
     } else {
         PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4, false>(grid, a, s)));
     }
+#endif
     return hipErrorInvalidValue;
 }
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s) {
+#ifdef PPCA_DEV_K10
+    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, true>(grid, a, s)));
+#else
     if (gram_i8()) {
         PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, true>(grid, a, s)));
     } else {
         PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, false>(grid, a, s)));
     }
+#endif
     return hipErrorInvalidValue;
 }
 

@@ -74,10 +74,12 @@ struct Posterior {
     static constexpr int KP = K * (K + 1) / 2;
     double L[KP];
 
+    // det M = pm * 2^pe with pm in [0.25, 1): the pivots are multiplied in two groups, each split by one
+    // frexp (safe unless five pivots alone overflow a double; the reference takes ln of the whole LU
+    // determinant, output_covariance.rs:115-121).  The caller decides when to take the logarithm.
     template <class GLoad>
-    PPCA_HD double factor(GLoad gload, double s2) {
-        double mant = 1.0;
-        int ex = 0;
+    PPCA_HD void factor(GLoad gload, double s2, double &pm, int &pe) {
+        double grp[2] = {1.0, 1.0};
 #pragma unroll
         for (int a = 0; a < K; ++a) {
 #pragma unroll
@@ -90,15 +92,16 @@ struct Posterior {
                     L[tri(a, c)] = s * L[tri(c, c)];
                 } else {
                     L[tri(a, a)] = fast_rsqrt(s);  // 1 / L_aa
-                    int e;
-                    mant *= frexp(s, &e);  // ln det M = ln prod(pivots), overflow-safe
-                    ex += e;
+                    grp[a >= (K + 1) / 2] *= s;    // pivot
                 }
             }
             sched_fence();  // keep the Gram loads of later rows from being hoisted (register pressure)
         }
-        return log(mant) + (double)ex * LN_2;
+        int e0, e1;
+        pm = frexp(grp[0], &e0) * frexp(grp[1], &e1);
+        pe = e0 + e1;
     }
+    PPCA_HD static double logdet(double pm, int pe) { return log(pm) + (double)pe * LN_2; }
 
     template <class BLoad>
     PPCA_HD void solve(BLoad bload, double (&z)[K], double &quad, double &zz) const {
@@ -167,6 +170,12 @@ PPCA_HD constexpr int column_owner(int K, int c, int nw) {
 PPCA_HD double sample_llk(double xx, double quad, double logdet, double s2, double ln_sigma, int m, int k) {
     if (m == 0) return 0.0;
     return -0.5 * ((xx - quad) / s2 + logdet + 2.0 * ln_sigma * (double)(m - k) + LN_2PI * (double)m);
+}
+// The same without the ln det M term and with 1/s2 precomputed (the fused EM pass adds the logarithms
+// of a whole run of samples at once).
+PPCA_HD double sample_llk_nolog(double xx, double quad, double inv_s2, double ln_sigma, int m, int k) {
+    if (m == 0) return 0.0;
+    return -0.5 * ((xx - quad) * inv_s2 + 2.0 * ln_sigma * (double)(m - k) + LN_2PI * (double)m);
 }
 
 // ---------------------------------------------------------------------------

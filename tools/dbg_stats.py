@@ -4,10 +4,10 @@ import numpy as np
 import ppca_rs_amd as P
 from ppca_rs_amd import _lib
 from oracle import ppca_oracle as o
-g = np.load(os.path.join(R, "tests/golden/wide_d256_k10.npz"))
+g = np.load(os.path.join(R, "tests/golden", sys.argv[1] if len(sys.argv) > 1 else "wide_d256_k10.npz"))
 x, s, c, mu = g["x"], float(g["s0"]), g["c0"], g["mu0"]
 m = P.PPCAModel(s, c, mu); ds = P.Dataset(x)
-d, k, kp = 256, 10, 55
+d, k = c.shape; kp = k * (k + 1) // 2
 L = _lib.lib().ppca_stats_len(d, k)
 got = np.empty(L); _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
 want = o.stats(x, s, c, mu)
