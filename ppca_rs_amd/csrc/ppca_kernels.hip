@@ -91,6 +91,21 @@ __device__ __forceinline__ int writelane(int dst, int sval) {
     asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
     return dst;
 }
+// As writelane, for a value produced by the SCALAR unit (no VALU-writes-SGPR hazard to pad).
+template <int LANE>
+__device__ __forceinline__ int writelane_s(int dst, int sval) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
+    return dst;
+}
+// mask bit of the lane ? v : 0.0 with the wave mask taken straight from its SGPR pair (a C++ select on
+// (mask >> lane) & 1 would rebuild the predicate with vector shifts).
+__device__ __forceinline__ double keep_if(double v, unsigned long long mask) {
+    const long long b = __double_as_longlong(v);
+    int lo, hi;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(lo) : "v"((int)b), "s"(mask));
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(hi) : "v"((int)(b >> 32)), "s"(mask));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -282,6 +297,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         dim_ok[q] = 64 * q + lane < d;
         jcl[q] = dim_ok[q] ? 64 * q + lane : d - 1;
     }
+    unsigned long long dimmask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dimmask[q] = __builtin_amdgcn_ballot_w64(dim_ok[q]);
     auto load_row = [&](int64_t tile, int r) {
         const int64_t row = tile * B + wave * RPW + r;
         const double *xrow = p.X + (row < n ? row : n - 1) * p.ldx;
@@ -315,7 +333,10 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // One row = 16 small pieces (each well under the 64 cycles of one fp64 MFMA) so that P4 can drop one
     // piece behind each of its MFMAs: 2q = classify + centre quarter q, 2q+1 = file its ballot / x~ / sums,
     // 8 = popcount, 9..14 = the six DPP steps of the row sum, 15 = row sum into its lane.
-    constexpr int STAGE_PIECES = 16;
+    // (the EM pass needs only the weighted SUM of the |x~_i|^2 -- sigma^2 and the total llk are linear in it --
+    //  so it keeps one running per-lane sum, reduced once per kernel, and skips pieces 9..15)
+    constexpr int STAGE_PIECES = EM ? 9 : 16;
+    double xx_run = 0.0;
     double pc_xt = 0.0, pc_xx = 0.0;
     unsigned long long pc_bal = 0ull;
     int pc_m = 0;
@@ -328,20 +349,28 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 pc_xx = 0.0;
                 pc_m = 0;
             }
-            const bool row_ok = t * B + ri < n;  // wave-uniform
+            // wave-uniform; the tile staged behind the workgroup's last P4 is another workgroup's (or none)
+            const bool row_ok = t < tile_end && t * B + ri < n;
             const double v = xr[r][q];
-            const bool fin = (bool)((int)row_ok & (int)dim_ok[q] & (int)__builtin_isfinite(v));
-            pc_xt = fin ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
-            pc_bal = __ballot(fin);
+            // the finite test's wave mask IS the ballot; validity is ANDed in on the scalar unit
+            // (|v| < inf as llvm.amdgcn.fcmp, predicate 4 = OLT: one v_cmp_lt_f64 straight into an SGPR pair;
+            //  ballot(isfinite) goes through v_cmp_class + v_cndmask + v_cmp_ne)
+            pc_bal = __builtin_amdgcn_fcmp(__builtin_fabs(v), __builtin_inf(), 4) & (row_ok ? dimmask[q] : 0ull);
+            pc_xt = keep_if(v - mu[q], pc_bal);  // select, never multiply (utils.rs:118-127)
         } else if constexpr (P < 8) {
             constexpr int q = P / 2;
-            st_wlo = writelane<4 * r + q>(st_wlo, (int)(unsigned)pc_bal);
-            st_whi = writelane<4 * r + q>(st_whi, (int)(unsigned)(pc_bal >> 32));
+            st_wlo = writelane_s<4 * r + q>(st_wlo, (int)(unsigned)pc_bal);
+            st_whi = writelane_s<4 * r + q>(st_whi, (int)(unsigned)(pc_bal >> 32));
             Xs[ri * XS + 64 * q + lane] = pc_xt;
             pc_xx += pc_xt * pc_xt;
             pc_m += __popcll(pc_bal);
         } else if constexpr (P == 8) {
             st_m = writelane<r>(st_m, pc_m);
+            if constexpr (EM) {
+                const int64_t row = t * B + ri;
+                const double wr = p.w ? p.w[row < n ? row : n - 1] : 1.0;  // wave-uniform (scalar load)
+                xx_run += wr * pc_xx;
+            }
         } else if constexpr (P == 9) {
             pc_xx += dpp_f64<0xB1, 0xF>(pc_xx);   // quad_perm [1,0,3,2]
         } else if constexpr (P == 10) {
@@ -368,7 +397,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         const double myxx = __longlong_as_double(((long long)st_xhi << 32) | (unsigned)st_xlo);
         if (lane < 4 * RPW) Ms[par * 4 * B + wave * 4 * RPW + lane] = myw;
         if (lane < RPW) {
-            xxs[wave * RPW + lane] = myxx;
+            if constexpr (!EM) xxs[wave * RPW + lane] = myxx;
             mcnt[wave * RPW + lane] = st_m;
         }
     };
@@ -591,7 +620,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 if (m > 0) sc_sq -= wgt * s2 * s2 * trpart;
             }
             if (wave == 0) {
-                const double xx = xxs[i];
+                const double xx = EM ? 0.0 : xxs[i];  // EM: the |x~|^2 terms are added once, in the epilogue
                 if constexpr (EM) {
                     double *zrow = wrow + 16 * NTP;  // W row = [w P (K') | 0.. | w z (K) | w | 0..]
 #pragma unroll
@@ -672,7 +701,10 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 constexpr int SLOTS = RT * NTM;
                 static_for<SLOTS>([&](auto i_tag) {
                     constexpr int i = decltype(i_tag)::value, r = i / NTM, t = i % NTM;
-                    const double am = ((mwc >> (((DW * wave) & 63) + 16 * r + l15)) & 1ull) ? 1.0 : 0.0;
+                    // am = bit ? 1.0 : 0.0 in two ops: sign-extended 1-bit field (0 / -1) & high word of 1.0
+                    const int sh = ((DW * wave) & 63) + 16 * r;
+                    const int am_hi = __builtin_amdgcn_sbfe((int)(unsigned)(mwc >> (sh & 32)), (sh & 31) + l15, 1) & 0x3FF00000;
+                    const double am = __hiloint2double(am_hi, 0);
                     accM[r][t] = mfma(am, bwc[t], accM[r][t]);
                     if constexpr (s < RPW) {  // the row's 16 pieces spread evenly over the step's MFMAs
                         constexpr int P0 = i * STAGE_PIECES / SLOTS, P1 = (i + 1) * STAGE_PIECES / SLOTS;
@@ -745,13 +777,20 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // scalars: deterministic reduction over the 32 solver lanes of each wave, then over the waves
     {
         const double sq_w = wave_sum(lane < B ? scl[wave * B + lane] : 0.0);
-        if (lane == 0) xxs[wave] = sq_w;  // xxs is free after the last tile
+        const double xx_w = wave_sum(xx_run);
+        if (lane == 0) {  // xxs is free after the last tile
+            xxs[wave] = sq_w;
+            xxs[NW + wave] = xx_w;
+        }
     }
     __syncthreads();
     if (wave == 0) {
         double v0 = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v0 += xxs[w];
+        double xx_tot = 0.0;  // sum_i w_i |x~_i|^2 (EM pass)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) xx_tot += xxs[NW + w];
         const int li = lane < B ? lane : 0;
         double sc_llk = scl[L_LLK + li];
         if constexpr (EM) sc_llk -= 0.5 * (log(scl[L_PM + li]) + scl[L_PX + li] * LN_2);
@@ -766,8 +805,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 sc = p.scal_part + (int64_t)blockIdx.x * 8;
             }
             sc[SC_SQERR] = v0;
-            sc[SC_DEVSQ] = v1;
-            sc[SC_LLK] = v2;
+            sc[SC_DEVSQ] = EM ? v1 + xx_tot : v1;
+            sc[SC_LLK] = EM ? v2 - 0.5 * inv_s2 * xx_tot : v2;
             sc[SC_SUMW] = v3;
             sc[SC_NONEMPTY] = v4;
             sc[5] = 0.0;
