@@ -287,35 +287,74 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 
     const int64_t ntiles = (n + B - 1) / B;
     double xr[RPW][4];
-    // Unconditional loads from clamped (always valid) addresses, one scalar base per row and
-    // one lane offset per quarter: nothing between issue and first use, so the loads of a whole
-    // tile stay in flight behind P4.  Out-of-range rows/dims are masked when consumed in P1.
-    int jcl[4];
+    // Row loads are unconditional (clamped to real rows; nothing between issue and first use, so a whole
+    // tile's loads stay in flight); out-of-range rows / dims are masked when consumed in P1.
     bool dim_ok[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        dim_ok[q] = 64 * q + lane < d;
-        jcl[q] = dim_ok[q] ? 64 * q + lane : d - 1;
-    }
+    for (int q = 0; q < 4; ++q) dim_ok[q] = 64 * q + lane < d;
     unsigned long long dimmask[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) dimmask[q] = __builtin_amdgcn_ballot_w64(dim_ok[q]);
-    auto load_row = [&](int64_t tile, int r) {
-        const int64_t row = tile * B + wave * RPW + r;
-        const double *xrow = p.X + (row < n ? row : n - 1) * p.ldx;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xr[r][q] = xrow[jcl[q]];  // validity is applied when consumed (P1)
-    };
-    auto load_tile = [&](int64_t tile) {
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) load_row(tile, r);
-    };
     // Each workgroup walks a CONTIGUOUS run of tiles (consecutive 64 KB pieces of X share pages, unlike a
     // grid-strided walk that starts every tile 16 MB further on).
     const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
     const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
     const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
-    load_tile(tile_begin);
+    const int64_t nleft = n - tile_begin * B;
+    const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));  // rows from the workgroup's first row to the end
+    const double *Xwg = p.X + tile_begin * B * p.ldx;
+    const int lane_entry = lane;
+    // Row loads are buffer loads through a per-row descriptor (base = row start, extent = d doubles): the
+    // address is one scalar multiply-add, the lane offset one constant VGPR, the quarter an immediate --
+    // no vector address arithmetic, and dims past d read as zero.  Rows are indexed relative to the
+    // workgroup's first row so that the clamp to the last real row is a 32-bit scalar compare.
+    auto load_row = [&](int64_t tile, int r) {
+        const int rel = (int)(tile - tile_begin) * B + wave * RPW + r;
+        const int rc = rel < nrel ? rel : nrel - 1;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(Xwg + (int64_t)rc * p.ldx), 0, d * (int)sizeof(double), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // validity is applied when consumed (P1)
+            typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+            const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lane_entry * 8, 512 * q, 0);
+            xr[r][q] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+        }
+    };
+    auto load_tile = [&](int64_t tile) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) load_row(tile, r);
+    };
+    if (tile_begin < tile_end) load_tile(tile_begin);
+    // int8 Gram: the slice table of this wave's column tile (QS x 4 fragments of 16 B per lane, L2-resident)
+    // streams through two register sets in four digit pairs, high to low.  The table does not depend on the
+    // tile, so pair {7,6} of the NEXT tile is requested at the start of P4 and is long there when P2 begins;
+    // {5,4} is requested first thing in P2 (behind the mask-byte expansion), {3,2} and {1,0} as soon as a
+    // register set is free, and they land behind the fp64 b = X~ C loop.  Buffer loads: one scalar resource for the table, a scalar offset per fragment
+    // and one lane offset register.  (The wave's table base is made opaque per use: 32 loop-invariant
+    // scalar offsets would be hoisted, overflow the SGPR file and come back through v_readlane + s_nop 4.)
+    static_assert(!GI8 || QS == 8, "digit grouping below assumes 8 slices");
+    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
+    // Waves without a column tile (k' <= 48) run the same loads (out of range of the table: zeros) and MFMAs
+    // and skip only the final store: a run-time condition around the loads would make the fragment registers
+    // look live around the whole tile loop.
+    const bool gram_wave = GI8 && (NTP >= NW || wave < NTP);  // compile-time true when every wave owns a tile
+    constexpr bool PREFETCH_A = EM;  // (no P4 in the output passes: they request {7,6} at the start of P2 as well)
+    i4_t qbA[2][4];
+    auto load_pair = [&](i4_t(&dst)[2][4], int sl0) {
+        int qbase = wave * QS * 4 * 1024;
+        asm volatile("" : "+s"(qbase));
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16, qbase + ((sl0 + u) * 4 + kc) * 1024, 0);
+                dst[u][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+            }
+    };
+    if constexpr (GI8) {
+        if (PREFETCH_A) load_pair(qbA, 6);
+    }
 #ifdef PPCA_PHASE_TIMING
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
@@ -350,7 +389,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 pc_m = 0;
             }
             // wave-uniform; the tile staged behind the workgroup's last P4 is another workgroup's (or none)
-            const bool row_ok = t < tile_end && t * B + ri < n;
+            const bool row_ok = t < tile_end && (int)(t - tile_begin) * B + ri < nrel;
             const double v = xr[r][q];
             // the finite test's wave mask IS the ballot; validity is ANDed in on the scalar unit
             // (|v| < inf as llvm.amdgcn.fcmp, predicate 4 = OLT: one v_cmp_lt_f64 straight into an SGPR pair;
@@ -409,7 +448,6 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         }
         __syncthreads();
     }
-    const int lane_entry = lane;
     for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
         // The lane index is made opaque once per tile: everything derived from it (LDS addresses, shift
         // counts, column maps) is then recomputed per tile -- a few integer ops -- instead of being
@@ -431,41 +469,6 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         PPCA_STAMP(0)
         // ------------------------------------------------------------ P2
         {
-            // int8 Gram: the slice table of this wave's column tile (QS x 4 fragments of 16 B per lane,
-            // L2-resident) streams through registers in four digit pairs, high to low: {7,6} and {5,4} are
-            // requested now and land behind the fp64 b = X~ C loop; {3,2} and {1,0} reuse their registers as
-            // soon as a pair has been contracted.  (Three-digit groups kept 80 registers of fragments in
-            // flight across the b loop: hipcc spilled three of them to scratch with a vmcnt(0) each.)
-            static_assert(!GI8 || QS == 8, "digit grouping below assumes 8 slices");
-            // buffer loads: one scalar resource for the table, a scalar offset per fragment and ONE lane
-            // offset register -- no per-load vector addresses for hipcc to keep alive (and spill)
-            const __amdgpu_buffer_rsrc_t qrsrc =
-                __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
-            // (the wave's table base is made opaque per tile: 32 loop-invariant scalar offsets would be
-            // hoisted, overflow the SGPR file and come back through v_readlane + s_nop 4 each)
-            int qbase = wave * QS * 4 * 1024;
-            asm volatile("" : "+s"(qbase));
-            auto ldq = [&](int sl, int kc) {
-                typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane * 16, qbase + (sl * 4 + kc) * 1024, 0);
-                return i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
-            };
-            i4_t qbA[2][4], qbB[2][4];
-            const bool gram_wave = GI8 && wave < NTP;
-            double qs = 0.0;
-            if constexpr (GI8) {
-                if (gram_wave) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int kc = 0; kc < 4; ++kc) qbA[u][kc] = ldq(6 + u, kc);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int kc = 0; kc < 4; ++kc) qbB[u][kc] = ldq(4 + u, kc);
-                    qs = p.qscale[16 * wave + l15];
-                }
-            }
             const int rt = wave & 1, kq = wave >> 1;
             const int si = 16 * rt + l15;
             unsigned long long mw[WPS];
@@ -485,8 +488,79 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 cpb[t] = crow + pb[t];
             }
             const double *cpc = crow + colb;
+            // A = mask bytes: lane (sample = 16 rt + l15, dims 64 kc + 16 l4 .. +15); 4 bits -> 4 bytes
+            // by one multiply: (x * 0x204081) & 0x01010101 puts bit i of x into byte i.
+            i4_t af[GI8 ? 2 : 1][4];
+            double v[2][4];
+            // one digit pair: contract, then fold the (exact) integer digit sums -- |sum| <= 2^14, so two
+            // digits fit one i32 with room to spare -- into the running fp64 value, Horner in 128^2
+            auto group = [&](const i4_t(*qb)[4], bool first) {
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
+                for (int rt2 = 0; rt2 < 2; ++rt2) {
+                    i4_t ia[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        ia[u] = i4_t{0, 0, 0, 0};
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc)
+                            ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt2][kc], qb[u][kc], ia[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int part = ia[1][r] * 128 + ia[0][r];
+                        v[rt2][r] = first ? (double)part : v[rt2][r] * 16384.0 + (double)part;
+                    }
+                }
+            };
+            double qs = 0.0;
+            i4_t qbB[2][4];
+            if constexpr (GI8) {
+                {
+                    if (!PREFETCH_A) load_pair(qbA, 6);
+                    load_pair(qbB, 4);
+                    if (gram_wave) qs = p.qscale[16 * wave + l15];
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) {
+                            const unsigned bits = (unsigned)(Msc[(16 * rt2 + l15) * 4 + kc] >> (16 * l4)) & 0xFFFFu;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
+                        }
+                    group(qbA, true);   // digits {7,6}: requested during the previous P4
+                    load_pair(qbA, 2);
+                    group(qbB, false);  // digits {5,4}
+                    load_pair(qbB, 0);
+                }
+            }
+            if constexpr (GI8) {
+                // b = X~ C alone: operands of the next four k-steps are requested before the current four
+                // MFMAs issue (hipcc otherwise reads each pair right before its MFMAs and waits on LDS)
+                constexpr int CH = 4;
+                double axb[2][CH], cbb[2][CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    axb[0][u] = xrow[4 * u];
+                    cbb[0][u] = cpc[4 * u * CS];
+                }
+#pragma unroll
+                for (int c = 0; c < STEPS / CH; ++c) {
+                    if (c + 1 < STEPS / CH) {
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
+                            cbb[(c + 1) & 1][u] = cpc[4 * ((c + 1) * CH + u) * CS];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // (without the fences the reads sink back to their uses)
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) acc[NTP] = mfma(axb[c & 1][u], cbb[c & 1][u], acc[NTP]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < (GI8 ? 0 : STEPS); ++s) {
                 const double ax = xrow[4 * s];
                 if constexpr (!GI8) {
                     const double am = ((mw[s / 16] >> (4 * (s & 15) + l4)) & 1ull) ? 1.0 : 0.0;
@@ -497,52 +571,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 acc[NTP] = mfma(ax, cpc[4 * s * CS], acc[NTP]);
             }
             if constexpr (GI8) {
+                group(qbA, false);  // digits {3,2}
+                group(qbB, false);  // digits {1,0}
                 if (gram_wave) {
-                    // A = mask bytes: lane (sample = 16 rt + l15, dims 64 kc + 16 l4 .. +15); 4 bits -> 4 bytes
-                    // by one multiply: (x * 0x204081) & 0x01010101 puts bit i of x into byte i.
-                    i4_t af[2][4];
-#pragma unroll
-                    for (int rt2 = 0; rt2 < 2; ++rt2)
-#pragma unroll
-                        for (int kc = 0; kc < 4; ++kc) {
-                            const unsigned bits = (unsigned)(Msc[(16 * rt2 + l15) * 4 + kc] >> (16 * l4)) & 0xFFFFu;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
-                        }
-                    // one digit pair: contract, then fold the (exact) integer digit sums -- |sum| <= 2^14, so
-                    // two digits fit one i32 with room to spare -- into the running fp64 value, Horner in 128^2
-                    double v[2][4];
-                    auto group = [&](const i4_t(*qb)[4], bool first) {
-#pragma unroll
-                        for (int rt2 = 0; rt2 < 2; ++rt2) {
-                            i4_t ia[2];
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                ia[u] = i4_t{0, 0, 0, 0};
-#pragma unroll
-                                for (int kc = 0; kc < 4; ++kc)
-                                    ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt2][kc], qb[u][kc], ia[u], 0, 0, 0);
-                            }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int part = ia[1][r] * 128 + ia[0][r];
-                                v[rt2][r] = first ? (double)part : v[rt2][r] * 16384.0 + (double)part;
-                            }
-                        }
-                    };
-                    group(qbA, true);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int kc = 0; kc < 4; ++kc) qbA[u][kc] = ldq(2 + u, kc);
-                    group(qbB, false);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int kc = 0; kc < 4; ++kc) qbB[u][kc] = ldq(u, kc);
-                    group(qbA, false);
-                    group(qbB, false);
 #pragma unroll
                     for (int rt2 = 0; rt2 < 2; ++rt2)
 #pragma unroll
@@ -621,6 +652,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             }
             if (wave == 0) {
                 const double xx = EM ? 0.0 : xxs[i];  // EM: the |x~|^2 terms are added once, in the epilogue
+                // running sums: requested at the top of the block, needed at its end
+                const double run_dev = scl[L_DEV + i], run_llk = scl[L_LLK + i], run_w = scl[L_W + i], run_ne = scl[L_NE + i];
+                const double run_pm = scl[L_PM + i], run_px = scl[L_PX + i];
                 if constexpr (EM) {
                     double *zrow = wrow + 16 * NTP;  // W row = [w P (K') | 0.. | w z (K) | w | 0..]
 #pragma unroll
@@ -647,8 +681,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                         const bool use = m > 0 && row < n;  // wgt is 1 for real rows
                         sc_llk += use ? lk0 : 0.0;
                         int e;
-                        scl[L_PM + i] = frexp(scl[L_PM + i] * (use ? pm : 1.0), &e);
-                        scl[L_PX + i] += (double)(e + (use ? pe : 0));
+                        scl[L_PM + i] = frexp(run_pm * (use ? pm : 1.0), &e);
+                        scl[L_PX + i] = run_px + (double)(e + (use ? pe : 0));
                     }
                     sc_w += wgt;
                 } else {
@@ -657,10 +691,10 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     sc_w += wgt;
                     if (p.llks && row < n) p.llks[row] = lk;
                 }
-                scl[L_DEV + i] += sc_dev;
-                scl[L_LLK + i] += sc_llk;
-                scl[L_W + i] += sc_w;
-                scl[L_NE + i] += sc_ne;
+                scl[L_DEV + i] = run_dev + sc_dev;
+                scl[L_LLK + i] = run_llk + sc_llk;
+                scl[L_W + i] = run_w + sc_w;
+                scl[L_NE + i] = run_ne + sc_ne;
             }
             if constexpr (EM) scl[wave * B + i] = sq_run + sc_sq;
         }
@@ -686,6 +720,11 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             PPCA_STAMP(4)
             // (b) S/U/totals += Mask^T [wP | wz | w], with the staging (P1) of the next tile's rows between the MFMAs
             stage_begin();
+            if constexpr (GI8) {
+                // the next tile's first digit pair (the table is tile-independent); holding the second pair
+                // across P4 as well spills 73 registers
+                if (PREFETCH_A) load_pair(qbA, 6);
+            }
             // One staging piece follows each MFMA.  Measured (tools/ubench_shadow.hip): v_mfma_f64 holds the
             // SIMD's VALU port for its 64 cycles -- no VALU instruction of this wave overlaps it, only LDS,
             // SALU and memory instructions do -- so this interleave hides the staging's LDS writes and the

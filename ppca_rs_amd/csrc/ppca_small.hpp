@@ -55,7 +55,12 @@ PPCA_HD void sched_fence() {
 
 PPCA_HD double fast_rsqrt(double s) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return rsqrt(s);
+    // v_rsq_f64 seed + one third-order correction: y (1 + e/2 + 3 e^2/8), e = 1 - s y^2 (residual ~ e^3).
+    // Pivots of M = sigma^2 I + G are positive normal numbers; the library routine's scaling for
+    // denormals / huge arguments is not needed and sat on the critical path of every column.
+    const double y = __builtin_amdgcn_rsq(s);
+    const double e = fma(-s * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
 #else
     return 1.0 / std::sqrt(s);
 #endif
@@ -77,25 +82,28 @@ struct Posterior {
     // det M = pm * 2^pe with pm in [0.25, 1): the pivots are multiplied in two groups, each split by one
     // frexp (safe unless five pivots alone overflow a double; the reference takes ln of the whole LU
     // determinant, output_covariance.rs:115-121).  The caller decides when to take the logarithm.
+    // Right-looking (outer-product) Cholesky: every column step is a set of INDEPENDENT multiply-adds on
+    // the trailing packed matrix.  The row-by-row form leaves each entry as one chain of dependent FMAs and
+    // ran at ~12 cycles per operation on one wave per SIMD instead of the ~6 the fp64 pipe issues at.
     template <class GLoad>
     PPCA_HD void factor(GLoad gload, double s2, double &pm, int &pe) {
         double grp[2] = {1.0, 1.0};
 #pragma unroll
-        for (int a = 0; a < K; ++a) {
+        for (int e = 0; e < KP; ++e) L[e] = gload(e);
 #pragma unroll
-            for (int c = 0; c <= a; ++c) {
-                double s = gload(tri(a, c));
-                if (c == a) s += s2;
+        for (int a = 0; a < K; ++a) L[tri(a, a)] += s2;
 #pragma unroll
-                for (int t = 0; t < c; ++t) s -= L[tri(a, t)] * L[tri(c, t)];
-                if (c < a) {
-                    L[tri(a, c)] = s * L[tri(c, c)];
-                } else {
-                    L[tri(a, a)] = fast_rsqrt(s);  // 1 / L_aa
-                    grp[a >= (K + 1) / 2] *= s;    // pivot
-                }
-            }
-            sched_fence();  // keep the Gram loads of later rows from being hoisted (register pressure)
+        for (int c = 0; c < K; ++c) {
+            const double piv = L[tri(c, c)];
+            grp[c >= (K + 1) / 2] *= piv;
+            const double inv = fast_rsqrt(piv);  // 1 / L_cc
+            L[tri(c, c)] = inv;
+#pragma unroll
+            for (int a = c + 1; a < K; ++a) L[tri(a, c)] *= inv;
+#pragma unroll
+            for (int a = c + 1; a < K; ++a)
+#pragma unroll
+                for (int b = c + 1; b <= a; ++b) L[tri(a, b)] -= L[tri(a, c)] * L[tri(b, c)];
         }
         int e0, e1;
         pm = frexp(grp[0], &e0) * frexp(grp[1], &e1);
@@ -103,25 +111,27 @@ struct Posterior {
     }
     PPCA_HD static double logdet(double pm, int pe) { return log(pm) + (double)pe * LN_2; }
 
+    // Substitutions are column-oriented for the same reason: once an unknown is final, the updates of all
+    // the remaining right-hand sides are independent.
     template <class BLoad>
     PPCA_HD void solve(BLoad bload, double (&z)[K], double &quad, double &zz) const {
+#pragma unroll
+        for (int a = 0; a < K; ++a) z[a] = bload(a);
         quad = 0.0;
 #pragma unroll
-        for (int a = 0; a < K; ++a) {
-            double s = bload(a);
+        for (int t = 0; t < K; ++t) {
+            z[t] *= L[tri(t, t)];  // y = L^-1 b
+            quad += z[t] * z[t];
 #pragma unroll
-            for (int t = 0; t < a; ++t) s -= L[tri(a, t)] * z[t];
-            z[a] = s * L[tri(a, a)];  // y = L^-1 b
-            quad += z[a] * z[a];
+            for (int a = t + 1; a < K; ++a) z[a] -= L[tri(a, t)] * z[t];
         }
         zz = 0.0;
 #pragma unroll
-        for (int a = K - 1; a >= 0; --a) {
-            double s = z[a];
+        for (int t = K - 1; t >= 0; --t) {
+            z[t] *= L[tri(t, t)];  // z = L^-T y
+            zz += z[t] * z[t];
 #pragma unroll
-            for (int t = a + 1; t < K; ++t) s -= L[tri(t, a)] * z[t];
-            z[a] = s * L[tri(a, a)];  // z = L^-T y
-            zz += z[a] * z[a];
+            for (int a = 0; a < t; ++a) z[a] -= L[tri(t, a)] * z[t];
         }
         sched_fence();
     }
@@ -130,37 +140,42 @@ struct Posterior {
     PPCA_HD double minv_column(int c, Store st) const {
         double u[K];
 #pragma unroll
-        for (int a = 0; a < K; ++a) {
-            if (a < c) continue;
-            double s = (a == c) ? 1.0 : 0.0;
+        for (int a = 0; a < K; ++a) u[a] = (a == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int t = 0; t < a; ++t)
-                if (t >= c) s -= L[tri(a, t)] * u[t];
-            u[a] = s * L[tri(a, a)];
+        for (int t = 0; t < K; ++t) {
+            if (t < c) continue;
+            u[t] *= L[tri(t, t)];
+#pragma unroll
+            for (int a = t + 1; a < K; ++a) u[a] -= L[tri(a, t)] * u[t];
         }
 #pragma unroll
-        for (int a = K - 1; a >= 0; --a) {
-            if (a < c) continue;
-            double s = u[a];
+        for (int t = K - 1; t >= 0; --t) {
+            if (t < c) continue;
+            u[t] *= L[tri(t, t)];  // x_t final; rows above c are not needed (symmetry)
+            st(t, c, u[t]);
 #pragma unroll
-            for (int t = a + 1; t < K; ++t) s -= L[tri(t, a)] * u[t];
-            u[a] = s * L[tri(a, a)];  // x_a overwrites u_a (only u_t, t > a, already final, are read)
-            st(a, c, u[a]);
+            for (int a = 0; a < t; ++a)
+                if (a >= c) u[a] -= L[tri(t, a)] * u[t];
         }
         sched_fence();
         return u[c];
     }
 };
 
-// Which of nw workers owns column c of M^-1: greedy balance of the (K - c)^2 solve costs.
+// Which of nw workers owns column c of M^-1: greedy balance of the column costs -- (K - c)^2 multiply-adds
+// of the two substitutions plus 4 (K - c) for forming and storing the second-moment entries -- with worker
+// 0 handicapped by what it alone does (z row, llk, noise terms: ~1.2 x a quarter of all columns at K = 10).
 PPCA_HD constexpr int column_owner(int K, int c, int nw) {
     int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int total = 0;
+    for (int cc = 0; cc < K; ++cc) total += (K - cc) * (K - cc) + 4 * (K - cc);
+    load[0] = total / nw;
     int own = 0;
     for (int cc = 0; cc <= c; ++cc) {
         own = 0;
         for (int w = 1; w < nw; ++w)
             if (load[w] < load[own]) own = w;
-        load[own] += (K - cc) * (K - cc);
+        load[own] += (K - cc) * (K - cc) + 4 * (K - cc);
     }
     return own;
 }

@@ -4,9 +4,10 @@
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int KIND, int NV, int NM>
+template <int KIND, int NV, int NM, int HALF = 0>
 __global__ void k_mix(double* out, long long* cyc, int iters) {
   __shared__ double lds[256 * 4];
+  if (HALF && (threadIdx.x & 32)) return;  // only lanes 0..31 of every wave stay active
   d4 acc[4];
   for (int i = 0; i < 4; ++i) acc[i] = d4{0, 0, 0, 0};
   int v[16];
@@ -112,6 +113,8 @@ int main() {
   MIX(8, 8, 4, "s_nop1+v_writelane"); MIX(8, 8, 0, "s_nop1+v_writelane");
   MIX(3, 4, 4, "ds_write_b64"); MIX(3, 8, 4, "ds_write_b64"); MIX(3, 8, 0, "ds_write_b64");
   MIX(4, 8, 4, "s_add_u32"); MIX(4, 16, 4, "s_add_u32"); MIX(4, 16, 0, "s_add_u32");
+#define MIXH(KIND, NV, NM, WHAT) run("lanes 0-31 only: 4 x [" #NM ">m MFMA + " #NV " x " WHAT "]", [&](double* o, long long* c, int n) { k_mix<KIND, NV, NM, 1><<<G, 256>>>(o, c, n); }, it)
+  MIXH(0, 8, 0, "v_fma_f64"); MIXH(1, 16, 0, "v_add_u32"); MIXH(5, 8, 0, "v_add_f64");
 #define ROLES(KIND, NV, NM, WHAT) run_roles("roles: waves0-3 " #NM " MFMA | waves4-7 4x" #NV " " WHAT, [&](double* o, long long* c, int n) { k_roles<KIND, NV, NM><<<G, 512>>>(o, c, n); }, it)
   ROLES(1, 8, 4, "v_add_u32"); ROLES(1, 16, 4, "v_add_u32"); ROLES(1, 16, 0, "v_add_u32"); ROLES(1, 0, 4, "-");
   ROLES(0, 8, 4, "v_fma_f64"); ROLES(0, 8, 0, "v_fma_f64");
