@@ -627,6 +627,121 @@ void ppca_oracle_stats(const double *x, const double *w, int64_t n, int d, int k
     free(states); free(covs); free(llks); free(co);
 }
 
+/* An honestly optimised CPU form of the same statistics pass (SURVEY.md 8d asks for it beside the literal
+ * port so that the GPU/CPU ratio is not only against the reference's structure): ONE sweep over the samples,
+ * per-sample Gram from a precomputed vech(c_j c_j^T) table, Cholesky instead of the subtractive Woodbury form,
+ * packed second moments, thread-private statistics summed at the end.  Same output layout as
+ * ppca_oracle_stats.  Not a restatement of any reference function: a baseline, checked against
+ * ppca_oracle_stats in tests/test_oracle.py. */
+void ppca_oracle_fused_stats(const double *x, const double *w, int64_t n, int d, int k, double sigma,
+                             const double *c, const double *mean, double *stats) {
+    const int kp = k * (k + 1) / 2;
+    const size_t o_cross = 0, o_s = (size_t)d * k, o_u = o_s + (size_t)d * kp, o_sx = o_u + (size_t)d * k,
+                 o_tot = o_sx + d, o_sc = o_tot + d, len = o_sc + 8;
+    const double s2 = sigma * sigma, ln_sigma = log(sigma), ln_2pi = 1.8378770664093453;
+    double *q = (double *)malloc(sizeof(double) * ((size_t)d * kp + 1));
+    for (int j = 0; j < d; ++j) {
+        int e = 0;
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b <= a; ++b, ++e) q[(size_t)j * kp + e] = c[(size_t)j * k + a] * c[(size_t)j * k + b];
+    }
+    for (size_t e = 0; e < len; ++e) stats[e] = 0.0;
+#pragma omp parallel
+    {
+        double *loc = (double *)calloc(len, sizeof(double));
+        double *g = (double *)malloc(sizeof(double) * (size_t)(2 * kp + 3 * k + 1));
+        double *l = g + kp, *b = l + kp, *z = b + k, *u = z + k;
+        int *obs = (int *)malloc(sizeof(int) * (size_t)(d + 1));
+        double *xt = (double *)malloc(sizeof(double) * (size_t)(d + 1));
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            const double *xi = x + i * d;
+            const double wi = w ? w[i] : 1.0;
+            int m = 0;
+            double xx = 0.0;
+            for (int j = 0; j < d; ++j)
+                if (is_finite(xi[j])) {
+                    obs[m] = j;
+                    xt[m] = xi[j] - mean[j];
+                    xx += xt[m] * xt[m];
+                    ++m;
+                }
+            loc[o_sc + 3] += wi;
+            for (int e = 0; e < kp; ++e) g[e] = 0.0;
+            for (int a = 0; a < k; ++a) b[a] = 0.0;
+            for (int r = 0; r < m; ++r) {
+                const double *qj = q + (size_t)obs[r] * kp, *cj = c + (size_t)obs[r] * k;
+                for (int e = 0; e < kp; ++e) g[e] += qj[e];
+                for (int a = 0; a < k; ++a) b[a] += cj[a] * xt[r];
+            }
+            /* M = G + s2 I = L L^T (packed lower), ln det M */
+            double logdet = 0.0;
+            for (int a = 0; a < k; ++a)
+                for (int cc = 0; cc <= a; ++cc) {
+                    double sacc = g[a * (a + 1) / 2 + cc] + (a == cc ? s2 : 0.0);
+                    for (int t = 0; t < cc; ++t) sacc -= l[a * (a + 1) / 2 + t] * l[cc * (cc + 1) / 2 + t];
+                    if (a == cc) {
+                        logdet += log(sacc);
+                        l[a * (a + 1) / 2 + a] = 1.0 / sqrt(sacc);
+                    } else {
+                        l[a * (a + 1) / 2 + cc] = sacc * l[cc * (cc + 1) / 2 + cc];
+                    }
+                }
+            double quad = 0.0, zz = 0.0;
+            for (int a = 0; a < k; ++a) {
+                double sacc = b[a];
+                for (int t = 0; t < a; ++t) sacc -= l[a * (a + 1) / 2 + t] * z[t];
+                z[a] = sacc * l[a * (a + 1) / 2 + a];
+                quad += z[a] * z[a];
+            }
+            for (int a = k - 1; a >= 0; --a) {
+                double sacc = z[a];
+                for (int t = a + 1; t < k; ++t) sacc -= l[t * (t + 1) / 2 + a] * z[t];
+                z[a] = sacc * l[a * (a + 1) / 2 + a];
+                zz += z[a] * z[a];
+            }
+            /* g <- w (z z^T + s2 M^-1), packed; trace of M^-1 on the way */
+            double tr = 0.0;
+            for (int cc = 0; cc < k; ++cc) {
+                for (int a = cc; a < k; ++a) {
+                    double sacc = (a == cc) ? 1.0 : 0.0;
+                    for (int t = cc; t < a; ++t) sacc -= l[a * (a + 1) / 2 + t] * u[t];
+                    u[a] = sacc * l[a * (a + 1) / 2 + a];
+                }
+                for (int a = k - 1; a >= cc; --a) {
+                    double sacc = u[a];
+                    for (int t = a + 1; t < k; ++t) sacc -= l[t * (t + 1) / 2 + a] * u[t];
+                    u[a] = sacc * l[a * (a + 1) / 2 + a];
+                    g[a * (a + 1) / 2 + cc] = wi * (z[a] * z[cc] + s2 * u[a]);
+                }
+                tr += u[cc];
+            }
+            for (int a = 0; a < k; ++a) b[a] = wi * z[a];
+            for (int r = 0; r < m; ++r) {
+                const int j = obs[r];
+                double *sj = loc + o_s + (size_t)j * kp, *uj = loc + o_u + (size_t)j * k, *cj = loc + o_cross + (size_t)j * k;
+                for (int e = 0; e < kp; ++e) sj[e] += g[e];
+                for (int a = 0; a < k; ++a) {
+                    uj[a] += b[a];
+                    cj[a] += b[a] * xt[r];
+                }
+                loc[o_sx + j] += wi * xt[r];
+                loc[o_tot + j] += wi;
+            }
+            if (m > 0) {
+                loc[o_sc + 0] += wi * s2 * ((double)k - s2 * tr);           /* tr(C_o Sigma C_o^T) */
+                loc[o_sc + 1] += wi * (xx - quad - s2 * zz);                 /* |x~ - C_o z|^2 */
+                loc[o_sc + 2] += wi * -0.5 * ((xx - quad) / s2 + logdet + 2.0 * ln_sigma * (double)(m - k) + ln_2pi * (double)m);
+                loc[o_sc + 4] += 1.0;
+            }
+        }
+#pragma omp critical
+        for (size_t e = 0; e < len; ++e) stats[e] += loc[e];
+        free(loc); free(g); free(obs); free(xt);
+    }
+    free(q);
+}
+
 /* ------------------------------------------------------------ to_canonical */
 
 /* ppca_model.rs:398-425: C = U S V^T -> C' = U S, columns by descending singular

@@ -174,6 +174,17 @@ def stats(x, sigma, c, mean, w=None) -> np.ndarray:
     return out
 
 
+def fused_stats(x, sigma, c, mean, w=None) -> np.ndarray:
+    """The honestly optimised CPU form of the statistics pass (one sweep, Cholesky, OpenMP): a second CPU
+    baseline for bench.py, same layout as stats()."""
+    x = _a(x); sigma, c, mean = _model(sigma, c, mean)
+    n, d = x.shape; k = c.shape[1]
+    w = _a(w).ravel() if w is not None else None
+    out = np.empty(stats_len(d, k))
+    lib().ppca_oracle_fused_stats(_p(x), _p(w), C.c_int64(n), d, k, C.c_double(sigma), _p(c), _p(mean), _p(out))
+    return out
+
+
 def to_canonical(c) -> np.ndarray:
     c = _a(c)
     out = np.empty_like(c)

@@ -145,3 +145,16 @@ def test_mixture_oracle_consistency(oracle):
         cur = oracle.mix_llks(x, sig, cs, ms, lw).sum()
         assert cur >= prev - 1e-8 * abs(cur)
         prev = cur
+
+
+def test_fused_cpu_stats_match_literal_stats(oracle):
+    o = oracle
+    """bench.py's second CPU baseline (one-sweep Cholesky form) against the literal restatement's statistics."""
+    x, _, _ = o.synth(600, 40, 6, 0.35, 77)
+    rng = np.random.default_rng(5)
+    c0, mu0, w = rng.standard_normal((40, 6)), rng.standard_normal(40) * 0.1, rng.uniform(0.2, 2.0, 600)
+    x[3] = np.nan  # an all-masked sample
+    for weights in (None, w):
+        want = o.stats(x, 0.7, c0, mu0, weights)
+        got = o.fused_stats(x, 0.7, c0, mu0, weights)
+        assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
