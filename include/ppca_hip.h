@@ -210,6 +210,15 @@ int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models_
 int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
                  int32_t n_models, double *total_host, double *per_sample_host, double *log_posteriors_host);
 
+/* PPCAMix::smooth / extrapolate (mix.rs:245-265, through InferredMaskedMix::smoothed :404-412 and
+ * ::extrapolated :414-423) and the diagonal covariances around the mixture mean
+ * (smoothed_covariance_diagonal :447-461, extrapolated_covariance_diagonal :489-505): posterior-weighted
+ * sums over the components.  mode 0 smooth, 1 extrapolate, 2 smoothed covariance diagonal,
+ * 3 extrapolated covariance diagonal.  The output dataset carries no weights (the reference collects
+ * fresh samples). */
+int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
+                         int32_t n_models, int32_t mode, ppca_dataset **out);
+
 /* ------------------------------------------------------------------ debug */
 /* One v_mfma_f64_16x16x4_f64 on host-supplied A (16 x 4) and B (4 x 16), result
  * (16 x 16) written through the C/D lane map the kernels assume (unit test). */

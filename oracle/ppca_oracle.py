@@ -237,6 +237,40 @@ def mix_iterate(x, sigmas, cs, means, log_weights, w=None, prior: Optional[Prior
     return s_out, c_out, m_out, lw_out
 
 
+def covariance_diagonal(x, sigma, c, mean, mode: str) -> np.ndarray:
+    """smoothed_covariance_diagonal ppca_model.rs:485-508 / extrapolated_covariance_diagonal :542-577
+    (sigma^2 + <c_j Sigma_i, c_j>; observed dims -> 0 in the extrapolated form), from the oracle's own posteriors."""
+    x = _a(x); sigma_, c_, mean_ = _model(sigma, c, mean)
+    _, covs = infer(x, sigma, c, mean)
+    diag = np.einsum("ja,nab,jb->nj", c_, covs, c_) + float(sigma) ** 2
+    return diag if mode == "smooth" else np.where(np.isfinite(x), 0.0, diag)
+
+
+def mix_inferred(x, sigmas, cs, means, log_weights) -> dict:
+    """Literal numpy restatement of InferredMaskedMix's accessors (mix.rs:374-505) on top of the oracle's
+    per-component posteriors: state() weights by the LOG posterior (:374-380, as written upstream),
+    covariance() :383-396, smoothed :399-407, extrapolated :410-418, the two diagonal covariances :447-461 and
+    :485-505 (each around the corresponding mixture mean)."""
+    x = _a(x); sigmas, cs, means, lw, nm, d, k = _mix(sigmas, cs, means, log_weights)
+    lp = mix_infer_cluster(x, sigmas, cs, means, lw)
+    post = np.exp(lp)
+    inf = [infer(x, sigmas[c], cs[c], means[c]) for c in range(nm)]
+    zs = np.stack([i[0] for i in inf])
+    state = np.einsum("nc,cnk->nk", lp, zs)
+    cov = np.zeros((x.shape[0], k, k))
+    for c in range(nm):
+        dv = zs[c] - state
+        cov += post[:, c, None, None] * (inf[c][1] + dv[:, :, None] * dv[:, None, :])
+    out = {"log_posterior": lp, "state": state, "covariance": cov}
+    for mode in ("smooth", "extrapolate"):
+        val = [reconstruct(x, sigmas[c], cs[c], means[c], mode) for c in range(nm)]
+        mean = np.einsum("nc,cnj->nj", post, np.stack(val))
+        dg = [covariance_diagonal(x, sigmas[c], cs[c], means[c], mode) + (val[c] - mean) ** 2 for c in range(nm)]
+        out[mode] = mean
+        out[mode + "_covariance_diagonal"] = np.einsum("nc,cnj->nj", post, np.stack(dg))
+    return out
+
+
 def synth(n, d, k, mask_prob, seed, sigma_true=0.1, mean_scale=1.0):
     """Seeded generator mirroring sample_one (ppca_model.rs:164-181):
     y = C n1 + mean + sigma n2, entries dropped with probability mask_prob."""

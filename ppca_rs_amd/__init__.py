@@ -5,10 +5,10 @@ Dataset, Prior, PPCAModel (llk / llks / infer / smooth / extrapolate / iterate /
 iterate_with_prior / to_canonical), InferredMasked, PPCAMix and the trainers, over
 hand-written HIP kernels for gfx950 behind the C-ABI of include/ppca_hip.h.
 """
-from .api import (Dataset, DatasetChunks, InferredMasked, PosteriorSampler, PPCAMix, PPCAMixTrainer, PPCAModel,
-                  PPCATrainer, Prior, TrainMetrics)
+from .api import (Dataset, DatasetChunks, InferredMasked, InferredMaskedMix, PosteriorSampler, PosteriorSamplerMix, PPCAMix,
+                  PPCAMixTrainer, PPCAModel, PPCATrainer, Prior, TrainMetrics)
 from ._lib import PPCAError
 
 __version__ = "0.1.0"
-__all__ = ["Dataset", "DatasetChunks", "InferredMasked", "PosteriorSampler", "PPCAMix", "PPCAMixTrainer", "PPCAModel",
+__all__ = ["Dataset", "DatasetChunks", "InferredMasked", "InferredMaskedMix", "PosteriorSampler", "PosteriorSamplerMix", "PPCAMix", "PPCAMixTrainer", "PPCAModel",
            "PPCATrainer", "Prior", "TrainMetrics", "PPCAError", "__version__"]

@@ -707,6 +707,184 @@ class PPCAMix:
         new._models, new._lw = [m.to_canonical() for m in self._models], self._lw.copy()
         return new
 
+    # -- inference outputs (mix.rs:179-265; src/python_bindings.rs:645-672) ---------------------------
+    def infer(self, dataset: Dataset) -> "InferredMaskedMix":
+        """Posterior over the components and the per-component state posteriors (mix.rs:206-235)."""
+        return InferredMaskedMix(self, self.infer_cluster(dataset), [m.infer(dataset) for m in self._models])
+
+    def _mix_recon(self, dataset: Dataset, mode: int) -> Dataset:
+        ctx = dataset._ctx
+        devs, arr = self._handles(ctx)
+        h = C.c_void_p()
+        check(lib().ppca_mix_reconstruct(ctx.handle, dataset._h, arr, ptr(self._lw), len(devs), mode, C.byref(h)))
+        return Dataset._wrap(h, ctx)
+
+    def smooth(self, dataset: Dataset) -> Dataset:
+        """Posterior-weighted sum of the components' smoothed outputs, on the GPU (mix.rs:238-251, :404-412);
+        the result carries no weights, like the reference's."""
+        return self._mix_recon(dataset, 0)
+
+    filter_extrapolate = smooth
+
+    def extrapolate(self, dataset: Dataset) -> Dataset:
+        """mix.rs:254-265, :414-423"""
+        return self._mix_recon(dataset, 1)
+
+    def sample(self, dataset_size: int, mask_prob: float, seed: Optional[int] = None) -> Dataset:
+        """mix.rs:124-134: a component per sample from the prior weights, then that component's generative
+        process (component blocks are generated on the GPU and interleaved by a random permutation)."""
+        if not (0.0 <= mask_prob <= 1.0):
+            raise ValueError("invalid mask probability")
+        rng = np.random.default_rng(seed)
+        which = rng.choice(len(self._models), size=dataset_size, p=self.weights / self.weights.sum())
+        out = np.empty((dataset_size, self.output_size))
+        for c, m in enumerate(self._models):
+            idx = np.nonzero(which == c)[0]
+            if idx.size:
+                out[idx] = m.sample(idx.size, mask_prob, seed=int(rng.integers(0, 2 ** 63 - 1))).numpy()
+        return Dataset(out)
+
+    # -- serialisation (own container; bincode layout is a "next" row) ---------------------------------
+    def dump(self) -> bytes:
+        buf = io.BytesIO()
+        np.savez(buf, kind="ppca_rs_amd.PPCAMix", log_weights=self._lw, n_models=len(self._models),
+                 **{f"sigma_{i}": m._sigma for i, m in enumerate(self._models)},
+                 **{f"transform_{i}": m._c for i, m in enumerate(self._models)},
+                 **{f"mean_{i}": m._mean for i, m in enumerate(self._models)})
+        return buf.getvalue()
+
+    @staticmethod
+    def load(data: bytes) -> "PPCAMix":
+        try:
+            z = np.load(io.BytesIO(data), allow_pickle=False)
+            nm = int(z["n_models"])
+            return PPCAMix([PPCAModel(float(z[f"sigma_{i}"]), z[f"transform_{i}"], z[f"mean_{i}"]) for i in range(nm)],
+                           z["log_weights"])
+        except Exception as err:
+            raise Exception(str(err))
+
+    def __getstate__(self):
+        return self.dump()
+
+    def __setstate__(self, state):
+        o = PPCAMix.load(state)
+        self.__dict__.update(o.__dict__)
+
+    def __getnewargs__(self):
+        return (self.models, self.log_weights)
+
+
+class InferredMaskedMix:
+    """Batch of mixture posteriors (mix.rs:349-515; src/python_bindings.rs:713-885).  The per-sample inference
+    ran on the GPU (PPCAMix.infer); these accessors combine the already-inferred host arrays exactly as the
+    reference's do, quirks included."""
+
+    def __init__(self, mix: PPCAMix, log_posterior: np.ndarray, inferred: List["InferredMasked"]):
+        self._mix, self._lp, self._inf = mix, log_posterior, inferred
+
+    def log_posteriors(self) -> np.ndarray:
+        if self._lp.shape[0] == 0:
+            return np.zeros((0, 0))
+        return self._lp.copy()
+
+    def posteriors(self) -> np.ndarray:
+        if self._lp.shape[0] == 0:
+            return np.zeros((0, 0))
+        return np.exp(self._lp)
+
+    def sub_states(self) -> List["InferredMasked"]:
+        return list(self._inf)
+
+    def _state_stack(self) -> np.ndarray:  # (K, N, k)
+        return np.stack([i._states for i in self._inf])
+
+    def states(self) -> np.ndarray:
+        """mix.rs:374-380 -- as written upstream the components are weighted by the LOG posterior."""
+        if self._lp.shape[0] == 0:
+            return np.zeros((0, 0))
+        return np.einsum("nc,cnk->nk", self._lp, self._state_stack())
+
+    def covariances(self) -> List[np.ndarray]:
+        """mix.rs:383-396: sum_c post_c (Sigma_c + (z_c - mean)(z_c - mean)^T), mean = states()."""
+        mean, post, zs = self.states(), np.exp(self._lp), self._state_stack()
+        out = []
+        for i in range(self._lp.shape[0]):
+            acc = 0.0
+            for c, inf in enumerate(self._inf):
+                dv = zs[c, i] - mean[i]
+                acc = acc + post[i, c] * (inf._covs[i] + np.outer(dv, dv))
+            out.append(acc)
+        return out
+
+    def _weighted(self, per_model: List[np.ndarray]) -> np.ndarray:
+        return np.einsum("nc,cnj->nj", np.exp(self._lp), np.stack(per_model))
+
+    def smoothed(self, ppca: PPCAMix) -> Dataset:
+        """mix.rs:399-407"""
+        return Dataset(np.ascontiguousarray(self._weighted([i.smoothed(m).numpy() for i, m in zip(self._inf, ppca._models)])))
+
+    def extrapolated(self, ppca: PPCAMix, dataset: Dataset) -> Dataset:
+        """mix.rs:410-418"""
+        return Dataset(np.ascontiguousarray(
+            self._weighted([i.extrapolated(m, dataset).numpy() for i, m in zip(self._inf, ppca._models)])))
+
+    def _cov_sum(self, means: List[np.ndarray], covs: List[List[np.ndarray]]) -> List[np.ndarray]:
+        post = np.exp(self._lp)
+        mean = np.einsum("nc,cnj->nj", post, np.stack(means))
+        out = []
+        for i in range(self._lp.shape[0]):
+            acc = 0.0
+            for c in range(len(self._inf)):
+                dv = means[c][i] - mean[i]
+                acc = acc + post[i, c] * (covs[c][i] + np.outer(dv, dv))
+            out.append(acc)
+        return out
+
+    def smoothed_covariances(self, ppca: PPCAMix) -> List[np.ndarray]:
+        """mix.rs:426-440 -- d x d per sample."""
+        return self._cov_sum([i.smoothed(m).numpy() for i, m in zip(self._inf, ppca._models)],
+                             [i.smoothed_covariances(m) for i, m in zip(self._inf, ppca._models)])
+
+    def smoothed_covariances_diagonal(self, ppca: PPCAMix) -> Dataset:
+        """mix.rs:447-461"""
+        sm = [i.smoothed(m).numpy() for i, m in zip(self._inf, ppca._models)]
+        mean = self._weighted(sm)
+        dg = [i.smoothed_covariances_diagonal(m).numpy() + (s - mean) ** 2 for i, m, s in zip(self._inf, ppca._models, sm)]
+        return Dataset(np.ascontiguousarray(self._weighted(dg)))
+
+    def extrapolated_covariances(self, ppca: PPCAMix, dataset: Dataset) -> List[np.ndarray]:
+        """mix.rs:464-477 -- as written upstream each component contributes its SMOOTHED covariance."""
+        return self._cov_sum([i.extrapolated(m, dataset).numpy() for i, m in zip(self._inf, ppca._models)],
+                             [i.smoothed_covariances(m) for i, m in zip(self._inf, ppca._models)])
+
+    def extrapolated_covariances_diagonal(self, ppca: PPCAMix, dataset: Dataset) -> Dataset:
+        """mix.rs:485-505"""
+        ex = [i.extrapolated(m, dataset).numpy() for i, m in zip(self._inf, ppca._models)]
+        mean = self._weighted(ex)
+        dg = [i.extrapolated_covariances_diagonal(m, dataset).numpy() + (e - mean) ** 2
+              for i, m, e in zip(self._inf, ppca._models, ex)]
+        return Dataset(np.ascontiguousarray(self._weighted(dg)))
+
+    def posterior_sampler(self) -> "PosteriorSamplerMix":
+        """mix.rs:508-518"""
+        return PosteriorSamplerMix(np.exp(self._lp), [i.posterior_sampler() for i in self._inf])
+
+
+class PosteriorSamplerMix:
+    """mix.rs:521-537; src/python_bindings.rs:887-905: a component per sample from its posterior, then a draw
+    from that component's state posterior pushed through its model."""
+
+    def __init__(self, posteriors: np.ndarray, samplers: List["PosteriorSampler"]):
+        self._post, self._samplers = posteriors, samplers
+
+    def sample(self, seed: Optional[int] = None) -> Dataset:
+        rng = np.random.default_rng(seed)
+        n = self._post.shape[0]
+        p = self._post / self._post.sum(axis=1, keepdims=True)
+        which = (rng.random((n, 1)) > np.cumsum(p, axis=1)).sum(axis=1).clip(0, p.shape[1] - 1)
+        draws = [s.sample(seed=int(rng.integers(0, 2 ** 63 - 1))).numpy() for s in self._samplers]
+        return Dataset(np.ascontiguousarray(np.stack(draws)[which, np.arange(n)]))
+
 
 @dataclass
 class PPCAMixTrainer:

@@ -986,6 +986,60 @@ extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *con
     return PPCA_OK;
 }
 
+extern "C" int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
+                                    int32_t n_models, int32_t mode, ppca_dataset **out) {
+    if (!ctx || !log_weights || !out) return fail(PPCA_ERR_INVALID, "null argument");
+    if (mode < 0 || mode > 3) return fail(PPCA_ERR_INVALID, "mode must be 0..3");
+    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
+    if (int rc = mix_check(ds, models, n_models)) return rc;
+    if (int rc = use_device(ctx)) return rc;
+    const int64_t n = ds->n;
+    const int d = ds->d, nm = n_models;
+    auto nd = std::make_unique<ppca_dataset>();
+    nd->ctx = ctx;
+    nd->n = n;
+    nd->d = d;  // weights are NOT carried over: mix.rs:245-265 collects fresh samples
+    if (int rc = dev_alloc(sizeof(double) * (size_t)std::max<int64_t>(n, 1) * d, &nd->xbuf)) return rc;
+    nd->X = static_cast<const double *>(nd->xbuf->p);
+    if (n == 0) {
+        *out = nd.release();
+        return PPCA_OK;
+    }
+    BufRef llk, u, lse, lp;
+    if (int rc = mix_posteriors(ctx, ds, models, log_weights, nm, llk, u, lse, &lp)) return rc;
+    const double *logpost = static_cast<const double *>(lp->p);
+    double *o = static_cast<double *>(nd->xbuf->p);
+    struct Tmp {  // frees the per-component output on every exit path
+        ppca_dataset *p = nullptr;
+        ~Tmp() { if (p) ppca_dataset_free(p); }
+    };
+    const int vmode = mode & 1;  // 0 smooth-like, 1 extrapolate-like
+    BufRef meanbuf;
+    double *mean = nullptr;
+    if (mode >= 2) {  // the diagonals are taken around the mixture mean (:448, :495): first pass
+        if (int rc = dev_alloc(sizeof(double) * (size_t)n * d, &meanbuf)) return rc;
+        mean = static_cast<double *>(meanbuf->p);
+    }
+    double *first_target = mode >= 2 ? mean : o;
+    for (int c = 0; c < nm; ++c) {
+        Tmp val;
+        if (int rc = recon_common(ctx, ds, models[c], vmode, &val.p)) return rc;
+        HIP_TRY(launch_mix_accumulate(first_target, val.p->X, nullptr, nullptr, logpost, c, nm, n, d, c == 0, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (mode >= 2) {
+        for (int c = 0; c < nm; ++c) {
+            Tmp val, dg;
+            if (int rc = recon_common(ctx, ds, models[c], vmode, &val.p)) return rc;
+            if (int rc = recon_common(ctx, ds, models[c], 2 + vmode, &dg.p)) return rc;
+            HIP_TRY(launch_mix_accumulate(o, dg.p->X, val.p->X, mean, logpost, c, nm, n, d, c == 0, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    *out = nd.release();
+    return PPCA_OK;
+}
+
 // ------------------------------------------------------------------ debug
 extern "C" int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const double *b4x16, double *out16x16) {
     if (!ctx || !a16x4 || !b4x16 || !out16x16) return fail(PPCA_ERR_INVALID, "null argument");

@@ -74,6 +74,8 @@ hipError_t generic_finalize(int k, int d, const double *stats, const double *mod
 // mixture helpers
 // llk: [n_models][n]; logw: [n_models]; w nullable.  Writes u: [n_models][n] =
 // ln w_i + log posterior_ic (-inf when w_i <= 0) and lse[n] (mixture llk per sample).
+hipError_t launch_mix_accumulate(double *out, const double *a, const double *dev, const double *mean,
+                                 const double *logpost, int c, int nm, int64_t n, int d, int first, hipStream_t s);
 hipError_t launch_mix_posteriors(const double *llk, const double *logw_dev, const double *w, int64_t n, int nm,
                                  double *u, double *lse, double *logpost, hipStream_t s);
 hipError_t launch_reduce_max(const double *v, int64_t n, double *out_scalar, double *work, hipStream_t s);

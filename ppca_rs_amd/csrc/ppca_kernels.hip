@@ -1276,6 +1276,28 @@ hipError_t launch_reduce_sum(const double *v, const double *w, int64_t n, double
                        (int64_t)blocks, out_scalar);
     return hipGetLastError();
 }
+// Posterior-weighted accumulation over mixture components (mix.rs:404-423, :447-461, :489-505):
+//   out (first ? = : +=) exp(logpost[i][c]) * (dev ? a + (dev - mean)^2 : a)
+__global__ void mix_accumulate_kernel(double *out, const double *a, const double *dev, const double *mean,
+                                      const double *logpost, int c, int nm, int64_t n, int d, int first) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    const int64_t i = idx / d;
+    const double wgt = exp(logpost[i * nm + c]);
+    double v = a[idx];
+    if (dev) {
+        const double t = dev[idx] - mean[idx];
+        v += t * t;
+    }
+    out[idx] = first ? wgt * v : out[idx] + wgt * v;
+}
+hipError_t launch_mix_accumulate(double *out, const double *a, const double *dev, const double *mean,
+                                 const double *logpost, int c, int nm, int64_t n, int d, int first, hipStream_t s) {
+    if (n <= 0 || d <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mix_accumulate_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, s, out, a, dev, mean,
+                       logpost, c, nm, n, d, first);
+    return hipGetLastError();
+}
 hipError_t launch_exp_shift(const double *v, const double *max_dev, int64_t n, double *out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(exp_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, max_dev, n, out);

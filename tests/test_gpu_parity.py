@@ -223,6 +223,55 @@ def test_mixture_against_oracle(P, oracle):
         assert _rel(mix.log_weights, lw) < RTOL
 
 
+def test_mixture_inference_outputs_against_oracle(P, oracle):
+    """PPCAMix.infer / smooth / extrapolate and the InferredMaskedMix accessors (mix.rs:179-265,
+    :352-515) -- GPU per-component inference + posterior-weighted combination vs the oracle's restatement."""
+    rng = np.random.default_rng(19)
+    d, k, nm, n = 20, 3, 3, 600
+    x = np.concatenate([oracle.synth(n // nm, d, k, 0.3, 500 + c_, mean_scale=2.0)[0] for c_ in range(nm)])
+    x[7] = np.nan  # an all-masked sample
+    sig = np.array([0.8, 1.1, 0.6])
+    cs = rng.standard_normal((nm, d, k))
+    ms = rng.standard_normal((nm, d))
+    lw = np.log(np.array([0.5, 0.2, 0.3]))
+    want = oracle.mix_inferred(x, sig, cs, ms, lw)
+    w = rng.uniform(0.5, 2.0, x.shape[0])
+    ds = P.Dataset(x, w)
+    mix = P.PPCAMix([P.PPCAModel(sig[c_], cs[c_], ms[c_]) for c_ in range(nm)], lw)
+    sm, ex = mix.smooth(ds), mix.extrapolate(ds)
+    assert _rel(sm.numpy(), want["smooth"]) < 1e-8 and _rel(ex.numpy(), want["extrapolate"]) < 1e-8
+    ob = np.isfinite(x)
+    assert np.abs(ex.numpy()[ob] - x[ob]).max() < 1e-12 * np.abs(x[ob]).max()  # posteriors sum to one
+    assert np.all(sm.weights() == 1.0)  # the reference's mixture outputs drop the weights (mix.rs:245-265)
+    assert np.all(np.isfinite(sm.numpy()))
+    inf = mix.infer(ds)
+    assert _rel(inf.log_posteriors(), want["log_posterior"]) < 1e-8
+    assert _rel(inf.posteriors().sum(axis=1), np.ones(x.shape[0])) < 1e-12
+    assert _rel(inf.states(), want["state"]) < 1e-8
+    assert _rel(np.array(inf.covariances()), want["covariance"]) < 1e-8
+    assert _rel(inf.smoothed(mix).numpy(), want["smooth"]) < 1e-8
+    assert _rel(inf.extrapolated(mix, ds).numpy(), want["extrapolate"]) < 1e-8
+    assert _rel(inf.smoothed_covariances_diagonal(mix).numpy(), want["smooth_covariance_diagonal"]) < 1e-8
+    assert _rel(inf.extrapolated_covariances_diagonal(mix, ds).numpy(), want["extrapolate_covariance_diagonal"]) < 1e-8
+    # device-side diagonals (ppca_mix_reconstruct modes 2 and 3) agree with the accessor path
+    assert _rel(mix._mix_recon(ds, 2).numpy(), want["smooth_covariance_diagonal"]) < 1e-8
+    assert _rel(mix._mix_recon(ds, 3).numpy(), want["extrapolate_covariance_diagonal"]) < 1e-8
+    # full covariances: diagonal of the d x d matrices = the diagonal accessor; extrapolated uses the smoothed
+    # component covariances, as written upstream (mix.rs:464-477)
+    full = np.array(inf.smoothed_covariances(mix)[:5])
+    assert _rel(np.einsum("njj->nj", full), want["smooth_covariance_diagonal"][:5]) < 1e-8
+    assert len(inf.extrapolated_covariances(mix, ds)) == x.shape[0]
+    # samplers: shapes, determinism under a seed, round trip of the container
+    s1, s2 = inf.posterior_sampler().sample(seed=4).numpy(), inf.posterior_sampler().sample(seed=4).numpy()
+    assert s1.shape == x.shape and np.array_equal(s1, s2)
+    gen = mix.sample(500, 0.2, seed=5).numpy()
+    assert gen.shape == (500, d) and 0.1 < np.isnan(gen).mean() < 0.3
+    back = P.PPCAMix.load(mix.dump())
+    assert _rel(back.llks(ds), mix.llks(ds)) < 1e-14
+    import pickle
+    assert _rel(pickle.loads(pickle.dumps(mix)).log_weights, mix.log_weights) < 1e-15
+
+
 def test_full_size_properties(P):
     """BASELINE config 2 at full size (N = 1M, d = 256, k = 10, 30 % masked): size-independent
     properties -- EM monotonicity, shard additivity of the statistics (the multi-GPU invariant),
