@@ -68,6 +68,7 @@ struct ppca_ctx {
     bool own_stream = false;
     int n_cu = 256;
     bool timing = false;
+    int skip_llk = 0;  // internal: set around the mixture's component EM steps (PassArgs::no_llk)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     BufRef part;  // per-workgroup partial statistics
     size_t part_cap = 0;
@@ -541,6 +542,7 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
     a.d = ds->d;
     a.model = model->p();
     a.part = static_cast<double *>(ctx->part->p);
+    a.no_llk = ctx->skip_llk;
     if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
     a.qscale = static_cast<double *>(ctx->qtab->p);
     a.qtab = reinterpret_cast<signed char *>(a.qscale + 64);
@@ -972,7 +974,9 @@ extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *con
         logsum[c] = std::log(h[1]) + h[0];
         ppca_dataset *wds = nullptr;
         if (int rc = ppca_dataset_with_weights(ds, nullptr, static_cast<double *>(wc->p), &wds)) return rc;
+        ctx->skip_llk = 1;  // the component steps' own llk is never read (the mixture llk came from the llks above)
         int rc = ppca_em_step(ctx, wds, models_in[c], prior, models_out[c], nullptr);  // :326-328
+        ctx->skip_llk = 0;
         if (rc == PPCA_OK) rc = ppca_ctx_synchronize(ctx);
         ppca_dataset_free(wds);
         if (rc) return rc;

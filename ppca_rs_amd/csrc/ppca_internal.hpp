@@ -38,6 +38,8 @@ struct PassArgs {
     int recon_mode;       // 0 smooth, 1 extrapolate, 2 smoothed cov diag, 3 extrapolated cov diag
     signed char *qtab;    // int8 Gram slice table of the current model (written by the launcher's qprep)
     double *qscale;       // its 64 dequantisation multipliers
+    int no_llk;           // EM mode: the caller does not read SC_LLK (mixture component steps): skip the
+                          // per-sample logarithm of the weighted path
     double *dbg;          // diagnostic builds (-DPPCA_PHASE_TIMING): [grid][4] phase cycle sums
 };
 

@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 if constexpr (EM) {
                     const double lk0 = sample_llk_nolog(xx, quad, inv_s2, lnsig, m, K);
                     if (p.w) {
-                        sc_llk += wgt * (m > 0 ? lk0 - 0.5 * Posterior<K>::logdet(pm, pe) : 0.0);
+                        if (!p.no_llk) sc_llk += wgt * (m > 0 ? lk0 - 0.5 * Posterior<K>::logdet(pm, pe) : 0.0);
                     } else {
                         const bool use = m > 0 && row < n;  // wgt is 1 for real rows
                         sc_llk += use ? lk0 : 0.0;
