@@ -246,6 +246,14 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     }
     for (int idx = tid; idx < B * WS; idx += THREADS) Ws[idx] = 0.0;
 
+    double muo[4];  // means in the output pass's lane map (dim = 64 wave + 16 c4 + lane % 16)
+    if constexpr (!EM) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int j = 64 * (wave & 3) + 16 * c4 + l15;
+            muo[c4] = (j < d) ? mMean[j] : 0.0;
+        }
+    }
     double mu[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -770,38 +778,95 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #endif
             PPCA_STAMP(7)
         } else if (p.recon) {
-            // output pass: smooth / extrapolate (ppca_model.rs:454-463) or covariance
-            // diagonals (:485-508, :542-577); one row per wave iteration, lanes over dims
-            for (int ri = wave; ri < B; ri += NW) {
-                const int64_t row = tile * B + ri;
-                if (row >= n) break;
-                const double *wrow = Ws + ri * WS;
+            // Output pass on the fp64 MFMA: out (32 samples x 256 dims) = A (32 x kk) . B (kk x 256), wave w owning
+            // dims 64 w .. 64 w + 63 (four 16-dim tiles) of both 16-sample row tiles.
+            //   smooth / extrapolate (ppca_model.rs:454-463): A = z (K states), B = C^T; + mean
+            //   covariance diagonals (:485-508, :542-577): A = vech(Sigma_i) (K' entries), B_j = c_ja c_jb,
+            //   doubled off the diagonal (c_j^T Sigma c_j over the packed half); + sigma^2
+            // (the scalar form spent 2 K LDS reads per output element, 2 K^2 for the diagonals)
+            static_assert(EM || NW == 4, "output pass: four waves x four dim tiles");
+            constexpr int CT = 4;
+            const bool dg = p.recon_mode >= 2;
+            d4_t oacc[2][CT];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = 64 * q + lane;
-                    if (j >= d) continue;
-                    const bool obs = (Msc[ri * 4 + q] >> lane) & 1ull;
-                    const double *cj = Cs + j * CS;
-                    double out;
-                    if (p.recon_mode <= 1) {
-                        double sm_ = mu[q];
+            for (int rt2 = 0; rt2 < 2; ++rt2)
 #pragma unroll
-                        for (int a = 0; a < K; ++a) sm_ += cj[a] * wrow[a];
-                        out = (p.recon_mode == 1 && obs) ? p.X[row * p.ldx + j] : sm_;
-                    } else {
-                        double v = 0.0;
+                for (int c4 = 0; c4 < CT; ++c4) oacc[rt2][c4] = d4_t{0, 0, 0, 0};
+            const double *crow4[CT];
 #pragma unroll
-                        for (int a = 0; a < K; ++a) {
-                            double t = 0.0;
+            for (int c4 = 0; c4 < CT; ++c4) crow4[c4] = Cs + (64 * wave + 16 * c4 + l15) * CS;
+            if (!dg) {
 #pragma unroll
-                            for (int c = 0; c < K; ++c) t += wrow[K + (a >= c ? tri(a, c) : tri(c, a))] * cj[c];
-                            v += cj[a] * t;
-                        }
-                        out = v + s2;
-                        if (p.recon_mode == 3 && obs) out = 0.0;
+                for (int s = 0; s < (K + 3) / 4; ++s) {
+                    const int kx = 4 * s + l4;             // state index of this lane's operands
+                    const int ka = kx < K ? kx : K - 1;    // A: any finite value (B is zero there)
+                    const int kb = kx < K ? kx : K;        // B: column K of the C tile is all zeros
+                    double bo[CT];
+#pragma unroll
+                    for (int c4 = 0; c4 < CT; ++c4) bo[c4] = crow4[c4][kb];
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; ++rt2) {
+                        const double ao = Ws[(16 * rt2 + l15) * WS + ka];
+#pragma unroll
+                        for (int c4 = 0; c4 < CT; ++c4) oacc[rt2][c4] = mfma(ao, bo[c4], oacc[rt2][c4]);
                     }
-                    p.recon[row * (int64_t)d + j] = out;
                 }
+            } else {
+#pragma unroll
+                for (int s = 0; s < (KP + 3) / 4; ++s) {
+                    const int e = 4 * s + l4;              // packed index (a >= b) of this lane's operands
+                    int ea = 0;
+                    while ((ea + 1) * (ea + 2) / 2 <= e) ++ea;
+                    int eb = e - ea * (ea + 1) / 2;
+                    const double fac = (e < KP) ? (ea == eb ? 1.0 : 2.0) : 0.0;
+                    if (e >= KP) { ea = K; eb = K; }       // zero column
+                    const int ka = e < KP ? e : KP - 1;
+                    double bo[CT];
+#pragma unroll
+                    for (int c4 = 0; c4 < CT; ++c4) bo[c4] = fac * crow4[c4][ea] * crow4[c4][eb];
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; ++rt2) {
+                        const double ao = Ws[(16 * rt2 + l15) * WS + K + ka];
+#pragma unroll
+                        for (int c4 = 0; c4 < CT; ++c4) oacc[rt2][c4] = mfma(ao, bo[c4], oacc[rt2][c4]);
+                    }
+                }
+            }
+            // C/D map of v_mfma_f64_16x16x4: row (sample) = l4 + 4 r, column (dim) = l15: every store
+            // instruction writes four 128-byte runs.  Branch-free: the observed values of extrapolate are
+            // requested for all 32 elements first (clamped addresses), then everything is selected and stored
+            // (a load or `continue` inside the element loop puts a vmcnt(0) behind every single store).
+            const bool extra = p.recon_mode == 1, zero_obs = p.recon_mode == 3;
+            double xo[CT][2][4];
+            if (extra) {
+#pragma unroll
+                for (int c4 = 0; c4 < CT; ++c4) {
+                    const int j = 64 * wave + 16 * c4 + l15, jc = j < d ? j : d - 1;
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t row = tile * B + 16 * rt2 + l4 + 4 * r;
+                            xo[c4][rt2][r] = p.X[(row < n ? row : n - 1) * p.ldx + jc];  // bit-exact pass-through
+                        }
+                }
+            }
+#pragma unroll
+            for (int c4 = 0; c4 < CT; ++c4) {
+                const int j = 64 * wave + 16 * c4 + l15;
+                const double add = dg ? s2 : muo[c4];
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * rt2 + l4 + 4 * r;
+                        const int64_t row = tile * B + i;
+                        const bool obs = (Msc[i * 4 + wave] >> (16 * c4 + l15)) & 1ull;
+                        double out = oacc[rt2][c4][r] + add;
+                        if (extra) out = obs ? xo[c4][rt2][r] : out;
+                        if (zero_obs) out = obs ? 0.0 : out;
+                        if (row < n && j < d) p.recon[row * (int64_t)d + j] = out;
+                    }
             }
         }
         __syncthreads();
