@@ -58,9 +58,22 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: 
     return lib_path
 
 
+def build_example() -> str:
+    """examples/em_train: a compiled host (plain g++) that links libppca_hip.so through include/ppca_hip.h only."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "em_train.cpp")
+    out = os.path.join(root, "examples", "em_train")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return out
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src, "-L" + HERE, "-lppca_hip",
+                           "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    return out
+
+
 if __name__ == "__main__":
     if "--timing" in sys.argv:
         print(build(force=True, verbose=True, extra_flags=("-DPPCA_PHASE_TIMING",),
                     lib_path=os.path.join(HERE, "libppca_hip_timing.so")))
     else:
         print(build(force="--force" in sys.argv, verbose=True))
+        print(build_example())

@@ -54,3 +54,16 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "ppca_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_compiled_host_example_builds_and_links():
+    """examples/em_train.cpp: plain g++ against include/ppca_hip.h + libppca_hip.so (no Python, no torch in the
+    boundary).  Built here; run on the GPU by tests/test_gpu_parity.py::test_compiled_host_example_runs."""
+    import subprocess
+
+    from ppca_rs_amd import build
+
+    exe = build.build_example()
+    assert os.path.exists(exe)
+    needed = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libppca_hip.so" in needed and "libtorch" not in needed and "python" not in needed.lower()

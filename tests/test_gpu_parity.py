@@ -272,6 +272,23 @@ def test_mixture_inference_outputs_against_oracle(P, oracle):
     assert _rel(pickle.loads(pickle.dumps(mix)).log_weights, mix.log_weights) < 1e-15
 
 
+def test_compiled_host_example_runs():
+    """The C-ABI driven from a compiled host (examples/em_train.cpp): EM on the fused path, llk monotone, the
+    noise level of the generating model recovered."""
+    import subprocess
+
+    from ppca_rs_amd import build
+
+    exe = build.build_example()
+    out = subprocess.run([exe, "200000", "256", "10", "12"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("Masked PPCA iteration")]
+    llks = [float(l.split("llk=")[1]) for l in lines]
+    assert len(llks) == 12 and all(b >= a for a, b in zip(llks, llks[1:]))
+    sigma = float(out.stdout.split("fitted isotropic noise ")[1].split()[0])
+    assert 0.05 < sigma < 0.5
+
+
 def test_full_size_properties(P):
     """BASELINE config 2 at full size (N = 1M, d = 256, k = 10, 30 % masked): size-independent
     properties -- EM monotonicity, shard additivity of the statistics (the multi-GPU invariant),
