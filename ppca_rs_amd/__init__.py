@@ -8,7 +8,8 @@ hand-written HIP kernels for gfx950 behind the C-ABI of include/ppca_hip.h.
 from .api import (Dataset, DatasetChunks, InferredMasked, InferredMaskedMix, PosteriorSampler, PosteriorSamplerMix, PPCAMix,
                   PPCAMixTrainer, PPCAModel, PPCATrainer, Prior, TrainMetrics)
 from ._lib import PPCAError
+from .frames import DataFrameAdapter, DataFrameAdapterDescription
 
 __version__ = "0.1.0"
 __all__ = ["Dataset", "DatasetChunks", "InferredMasked", "InferredMaskedMix", "PosteriorSampler", "PosteriorSamplerMix", "PPCAMix", "PPCAMixTrainer", "PPCAModel",
-           "PPCATrainer", "Prior", "TrainMetrics", "PPCAError", "__version__"]
+           "PPCATrainer", "Prior", "TrainMetrics", "PPCAError", "DataFrameAdapter", "DataFrameAdapterDescription", "__version__"]

@@ -289,6 +289,29 @@ def test_compiled_host_example_runs():
     assert 0.05 < sigma < 0.5
 
 
+def test_dataframe_adapter_round_trip(P):
+    """DataFrame -> Dataset -> model -> DataFrame (python/ppca_rs/__init__.py:119-433)."""
+    import pandas as pd
+
+    rng = np.random.default_rng(8)
+    n_s, n_d = 300, 6
+    full = rng.standard_normal((n_s, 2)) @ rng.standard_normal((2, n_d)) + 0.05 * rng.standard_normal((n_s, n_d))
+    keep = rng.random((n_s, n_d)) < 0.8
+    si, di = np.nonzero(keep)
+    df = pd.DataFrame({"unit": si, "sensor": [f"s{j}" for j in di], "value": full[si, di]}).sample(frac=1.0, random_state=1)
+    ad = P.DataFrameAdapter.from_pandas(df, keys=["unit"], dimensions=["sensor"], metric="value")
+    x = ad.dataset.numpy()
+    assert x.shape == (n_s, n_d) and np.array_equal(np.isfinite(x), keep) and np.allclose(x[keep], full[keep])
+    model = P.PPCATrainer(ad.dataset).train(state_size=2, n_iters=15, quiet=True)
+    long = ad.convert_datasets({"seen": ad.dataset, "filled": model.extrapolate(ad.dataset)})
+    assert list(long.columns) == ["unit", "sensor", "seen", "filled"] and len(long) == n_s * n_d
+    merged = long.merge(df, on=["unit", "sensor"])
+    assert np.allclose(merged["filled"], merged["value"]) and np.allclose(merged["seen"], merged["value"])
+    assert long["filled"].notna().all() and long["seen"].isna().sum() == (~keep).sum()
+    again = ad.description().adapt_pandas(df)
+    assert np.array_equal(np.nan_to_num(again.dataset.numpy()), np.nan_to_num(x))
+
+
 def test_full_size_properties(P):
     """BASELINE config 2 at full size (N = 1M, d = 256, k = 10, 30 % masked): size-independent
     properties -- EM monotonicity, shard additivity of the statistics (the multi-GPU invariant),

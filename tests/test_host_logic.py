@@ -163,3 +163,41 @@ def test_prior_validation():
         Prior().with_mean_prior(np.zeros(3), np.zeros((3, 3)))
     p = Prior().with_transformation_precision(2.0)
     assert p.transformation_precision == 2.0 and Prior().transformation_precision == 0.0
+
+
+def test_dataframe_pivot_matches_reference_semantics():
+    """the long-format pivot behind DataFrameAdapter.from_pandas (python/ppca_rs/__init__.py:145-206)
+    against a direct per-group fill, the way the reference populates its matrix."""
+    import pandas as pd
+
+    from ppca_rs_amd import frames
+
+    rng = np.random.default_rng(3)
+    rows = []
+    for day in ["2024-01-03", "2024-01-01", "2024-01-02"]:
+        for shop in ["b", "a"]:
+            for prod, size in [("x", 1), ("y", 2), ("x", 2)]:
+                if rng.random() < 0.7:
+                    rows.append({"day": day, "shop": shop, "product": prod, "size": size, "sales": rng.normal()})
+    df = pd.DataFrame(rows)
+    mat, dim_idx, smp_idx, dims = frames.pivot_pandas(df, keys=["day", "shop"], dimensions=["product", "size"],
+                                                       dimension_idx=None, metric="sales")
+    assert dims == ["product", "size"]
+    assert [tuple(r) for r in dim_idx[["product", "size"]].values.tolist()] == \
+        sorted(set(map(tuple, df[["product", "size"]].values.tolist())))
+    want = np.full((len(smp_idx), len(dim_idx)), np.nan)
+    lookup = {tuple(r[:2]): int(r[2]) for r in dim_idx[["product", "size", frames.DIM]].values.tolist()}
+    for i, (_, chunk) in enumerate(df.groupby(["day", "shop"])):
+        for _, r in chunk.iterrows():
+            want[i, lookup[(r["product"], r["size"])]] = r["sales"]
+    assert np.array_equal(np.isnan(mat), np.isnan(want)) and np.allclose(np.nan_to_num(mat), np.nan_to_num(want))
+    assert smp_idx[["day", "shop"]].values.tolist() == sorted(map(list, {tuple(v) for v in df[["day", "shop"]].values.tolist()}))
+    # a given dimension index restricts (inner join) and fixes the dimension order
+    sub = dim_idx.iloc[[2, 0]].reset_index(drop=True).copy()
+    sub[frames.DIM] = [0, 1]
+    mat2, _, _, dims2 = frames.pivot_pandas(df, keys=["day", "shop"], dimensions=None, dimension_idx=sub, metric="sales")
+    assert dims2 == ["product", "size"] and mat2.shape[1] == 2
+    # description <-> json round trip
+    d = frames.DataFrameAdapterDescription(["day", "shop"], dims, "sales", dim_idx[dims].values.tolist())
+    back = frames.DataFrameAdapterDescription.from_json(d.to_json())
+    assert back == d and list(back.dimension_idx_pandas.columns) == [frames.DIM, "product", "size"]
