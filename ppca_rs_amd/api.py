@@ -16,6 +16,7 @@ from typing import Iterator, List, Literal, Optional, Sequence
 import numpy as np
 
 from . import _lib
+from . import wire as _wire
 from ._lib import check, f64, lib, ptr
 
 
@@ -139,8 +140,12 @@ class Dataset:
         check(lib().ppca_dataset_concat(ctx.handle, arr, len(datasets), C.byref(h)))
         return Dataset._wrap(h, ctx)
 
-    # dump/load: own container (npz); the reference's bincode layout is a "next" row
-    def dump(self) -> bytes:
+    # dump/load (src/python_bindings.rs:66-79).  Default container: npz (round trip verified here);
+    # format="bincode" writes the reference's bincode layout as restated in wire.py (parity unpinned: no real
+    # artefact to check against).  load() accepts both.
+    def dump(self, format: str = "npz") -> bytes:
+        if format == "bincode":
+            return _wire.dump_dataset(self.numpy(), self.weights())
         buf = io.BytesIO()
         np.savez(buf, kind="ppca_rs_amd.Dataset", data=self.numpy(), weights=self.weights())
         return buf.getvalue()
@@ -148,6 +153,9 @@ class Dataset:
     @staticmethod
     def load(data: bytes) -> "Dataset":
         try:
+            if bytes(data[:2]) != b"PK":
+                x, w = _wire.load_dataset(data)
+                return Dataset(x, w)
             z = np.load(io.BytesIO(data), allow_pickle=False)
             return Dataset(z["data"], z["weights"])
         except Exception as err:  # reference: bincode error -> Exception(str)
@@ -448,7 +456,10 @@ class PPCAModel:
         return PPCAModel(self._sigma, c, self._mean)
 
     # -- serialisation (own container; bincode layout is a "next" row) ------------
-    def dump(self) -> bytes:
+    def dump(self, format: str = "npz") -> bytes:
+        """src/python_bindings.rs:394-401; format="bincode": the reference's layout (wire.py, parity unpinned)."""
+        if format == "bincode":
+            return _wire.dump_model(self._sigma, self._c, self._mean)
         buf = io.BytesIO()
         np.savez(buf, kind="ppca_rs_amd.PPCAModel", isotropic_noise=self._sigma, transform=self._c, mean=self._mean)
         return buf.getvalue()
@@ -456,6 +467,8 @@ class PPCAModel:
     @staticmethod
     def load(data: bytes) -> "PPCAModel":
         try:
+            if bytes(data[:2]) != b"PK":
+                return PPCAModel(*_wire.load_model(data))
             z = np.load(io.BytesIO(data), allow_pickle=False)
             return PPCAModel(float(z["isotropic_noise"]), z["transform"], z["mean"])
         except Exception as err:
@@ -745,7 +758,9 @@ class PPCAMix:
         return Dataset(out)
 
     # -- serialisation (own container; bincode layout is a "next" row) ---------------------------------
-    def dump(self) -> bytes:
+    def dump(self, format: str = "npz") -> bytes:
+        if format == "bincode":
+            return _wire.dump_mix([(m._sigma, m._c, m._mean) for m in self._models], self._lw)
         buf = io.BytesIO()
         np.savez(buf, kind="ppca_rs_amd.PPCAMix", log_weights=self._lw, n_models=len(self._models),
                  **{f"sigma_{i}": m._sigma for i, m in enumerate(self._models)},
@@ -756,6 +771,9 @@ class PPCAMix:
     @staticmethod
     def load(data: bytes) -> "PPCAMix":
         try:
+            if bytes(data[:2]) != b"PK":
+                models, lw = _wire.load_mix(data)
+                return PPCAMix([PPCAModel(*m) for m in models], lw)
             z = np.load(io.BytesIO(data), allow_pickle=False)
             nm = int(z["n_models"])
             return PPCAMix([PPCAModel(float(z[f"sigma_{i}"]), z[f"transform_{i}"], z[f"mean_{i}"]) for i in range(nm)],

@@ -312,6 +312,22 @@ def test_dataframe_adapter_round_trip(P):
     assert np.array_equal(np.nan_to_num(again.dataset.numpy()), np.nan_to_num(x))
 
 
+def test_dump_load_both_containers(P):
+    """dump()/load() (src/python_bindings.rs:66-79, :388-401): own npz container and the restated bincode layout."""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((50, 33))
+    x[rng.random(x.shape) < 0.25] = np.nan
+    ds = P.Dataset(x, rng.uniform(0.5, 1.5, 50))
+    m = P.PPCAModel(0.3, rng.standard_normal((33, 4)), rng.standard_normal(33))
+    for fmt in ("npz", "bincode"):
+        d2, m2 = P.Dataset.load(ds.dump(fmt)), P.PPCAModel.load(m.dump(fmt))
+        assert np.array_equal(np.nan_to_num(d2.numpy()), np.nan_to_num(x)) and np.array_equal(d2.weights(), ds.weights())
+        assert m2.isotropic_noise == 0.3 and np.array_equal(m2.transform, m.transform) and np.array_equal(m2.mean, m.mean)
+        assert m2.llk(d2) == m.llk(ds)
+    with pytest.raises(Exception):
+        P.PPCAModel.load(m.dump("bincode")[:-5])
+
+
 def test_full_size_properties(P):
     """BASELINE config 2 at full size (N = 1M, d = 256, k = 10, 30 % masked): size-independent
     properties -- EM monotonicity, shard additivity of the statistics (the multi-GPU invariant),

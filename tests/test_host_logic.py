@@ -201,3 +201,44 @@ def test_dataframe_pivot_matches_reference_semantics():
     d = frames.DataFrameAdapterDescription(["day", "shop"], dims, "sales", dim_idx[dims].values.tolist())
     back = frames.DataFrameAdapterDescription.from_json(d.to_json())
     assert back == d and list(back.dimension_idx_pandas.columns) == [frames.DIM, "product", "size"]
+
+
+def test_bincode_layouts_against_hand_built_bytes():
+    """SURVEY 8f-3 (parity unpinned: no real artefact exists to compare with).  The layouts of wire.py against
+    byte strings assembled field by field from the crates' serde rules for the reference's toy model
+    (ppca_model.rs:647-656: C = [[1,1],[1,0],[0,1]]), plus round trips."""
+    import struct
+
+    from ppca_rs_amd import wire
+
+    c = np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]])
+    mean = np.array([0.5, -1.0, 2.0])
+    u64, f = (lambda v: struct.pack("<Q", v)), (lambda *v: struct.pack("<%dd" % len(v), *v))
+    want = (f(0.1)                                    # OutputCovariance.isotropic_noise
+            + u64(6) + f(1, 1, 0, 1, 0, 1)            # transform: VecStorage.data, column-major
+            + u64(3) + u64(2)                         # nrows (Dyn), ncols (Dyn)
+            + u64(3) + f(0.5, -1.0, 2.0) + u64(3))    # mean: data, nrows (Dyn); ncols Const<1> = unit
+    got = wire.dump_model(0.1, c, mean)
+    assert got == want and len(got) == 8 + 8 + 48 + 16 + 8 + 24 + 8
+    s2, c2, m2 = wire.load_model(got)
+    assert s2 == 0.1 and np.array_equal(c2, c) and np.array_equal(m2, mean)
+    # Dataset: two samples of d = 3, one masked entry; BitVec<u32> = [n blocks][blocks][nbits], bit i of block i / 32
+    x = np.array([[1.0, np.nan, 3.0], [4.0, 5.0, 6.0]])
+    sample0 = u64(3) + struct.pack("<3d", 1.0, float("nan"), 3.0) + u64(3) + u64(1) + struct.pack("<I", 0b101) + u64(3)
+    sample1 = u64(3) + f(4, 5, 6) + u64(3) + u64(1) + struct.pack("<I", 0b111) + u64(3)
+    want_ds = u64(2) + sample0 + sample1 + u64(2) + f(1.0, 2.0)
+    got_ds = wire.dump_dataset(x, np.array([1.0, 2.0]))
+    assert got_ds == want_ds
+    x2, w2 = wire.load_dataset(got_ds)
+    assert np.array_equal(np.isnan(x2), np.isnan(x)) and np.array_equal(np.nan_to_num(x2), np.nan_to_num(x))
+    assert np.array_equal(w2, [1.0, 2.0])
+    # wide rows (two mask blocks) and the mixture container round-trip
+    rng = np.random.default_rng(2)
+    xx = rng.standard_normal((7, 40))
+    xx[rng.random(xx.shape) < 0.3] = np.nan
+    x3, _ = wire.load_dataset(wire.dump_dataset(xx, np.ones(7)))
+    assert np.array_equal(np.isnan(x3), np.isnan(xx)) and np.array_equal(np.nan_to_num(x3), np.nan_to_num(xx))
+    models, lw = wire.load_mix(wire.dump_mix([(0.1, c, mean), (0.2, 2 * c, -mean)], np.log([0.25, 0.75])))
+    assert len(models) == 2 and models[1][0] == 0.2 and np.array_equal(models[1][1], 2 * c) and np.allclose(np.exp(lw), [0.25, 0.75])
+    with pytest.raises(ValueError):
+        wire.load_model(got[:-3])
