@@ -220,6 +220,14 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     constexpr int WPS = DPS / 64;        // mask words per split
     constexpr int RT = 16 / NW;          // accumulator row tiles (16 dims each) per wave in P4
     constexpr int DW = cfg::DP / NW;     // dims owned by a wave in P4
+    // Mask-side columns of P4: k' (vech P) + k (w z) + 1 (w).  When they overflow the k' tiles by at most four
+    // columns (k = 10: 66 = 4 x 16 + 2) the first PADS of [w z | w] ride in the padding of the last vech tile and
+    // the remaining SMALL_COLS go through v_mfma_f64_4x4x4_4b (four 4 x 4 x 4 blocks, 18 cycles) instead of a
+    // fifth 16-column tile of 64-cycle MFMAs: 16 + 4 instead of 20 big MFMAs per k-step and wave.
+    constexpr int PADS = 16 * NTP - KP;
+    constexpr int SMALL_COLS = K + 1 - PADS;
+    constexpr bool SPLIT = EM && NW == 4 && SMALL_COLS > 0 && SMALL_COLS <= 4 && PADS > 0;
+    constexpr int NTMB = SPLIT ? NTP : NTM;  // big (16-column) mask-side tiles
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(!GI8 || (NW == 4 && NTP <= 4), "int8 Gram: one wave per packed-column tile");
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -275,12 +283,14 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     const int colb = (l15 < K) ? l15 : K;
 
     d4_t accM[RT][NTM];
+    double accS[RT];  // SPLIT: the 4-column group, D lane = 16 i + 4 block + j (dim 4 block + i of the row tile, column j)
     d4_t accX[RT];
     if constexpr (EM) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
 #pragma unroll
             for (int t = 0; t < NTM; ++t) accM[r][t] = d4_t{0, 0, 0, 0};
+            accS[r] = 0.0;
             accX[r] = d4_t{0, 0, 0, 0};
         }
     }
@@ -668,6 +678,10 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #pragma unroll
                     for (int a = 0; a < K; ++a) zrow[a] = wgt * z[a];
                     zrow[K] = wgt;
+                    if constexpr (SPLIT) {  // the leading [w z | w] columns again, in the padding behind vech(P)
+#pragma unroll
+                        for (int a = 0; a < PADS; ++a) wrow[KP + a] = (a < K) ? wgt * z[a] : wgt;
+                    }
                     if (m > 0) {
                         sc_sq += wgt * s2 * (double)K;
                         sc_dev += wgt * (xx - quad - s2 * zz);  // |x~ - C_o z|^2  (:346)
@@ -738,22 +752,31 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             // SALU and memory instructions do -- so this interleave hides the staging's LDS writes and the
             // row-load latency, not its ALU work.  The B operands of step s+1 are read from LDS during step s.
             unsigned long long mwc = Msc[l4 * 4 + (DW * wave) / 64];
-            double bwc[NTM];
+            double bwc[NTMB], bsc = 0.0;
 #pragma unroll
-            for (int t = 0; t < NTM; ++t) bwc[t] = Ws[l4 * WS + 16 * t + l15];
+            for (int t = 0; t < NTMB; ++t) bwc[t] = Ws[l4 * WS + 16 * t + l15];
+            // B operand of the 4x4x4 blocks: lane = 16 k + 4 block + j -> W[sample 4 s + k][column j of the group];
+            // its A operand (lane = 16 k + 4 block + i -> dim 4 block + i, sample k) is the SAME register as the
+            // 16x16x4 tiles' (row = lane % 16, k = lane / 16): no extra mask expansion.
+            if constexpr (SPLIT) bsc = Ws[l4 * WS + 16 * NTP + PADS + (lane & 3)];
             static_for<8>([&](auto s_tag) {
                 constexpr int s = decltype(s_tag)::value;
                 unsigned long long mwn = 0ull;
-                double bwn[NTM];
-                constexpr int SLOTS = RT * NTM;
+                double bwn[NTMB], bsn = 0.0;
+                constexpr int PER_R = NTMB + (SPLIT ? 1 : 0);  // MFMAs per row tile and k-step
+                constexpr int SLOTS = RT * PER_R;
                 static_for<SLOTS>([&](auto i_tag) {
-                    constexpr int i = decltype(i_tag)::value, r = i / NTM, t = i % NTM;
+                    constexpr int i = decltype(i_tag)::value, r = i / PER_R, t = i % PER_R;
                     // am = bit ? 1.0 : 0.0 in two ops: sign-extended 1-bit field (0 / -1) & high word of 1.0
                     const int sh = ((DW * wave) & 63) + 16 * r;
                     const int am_hi = __builtin_amdgcn_sbfe((int)(unsigned)(mwc >> (sh & 32)), (sh & 31) + l15, 1) & 0x3FF00000;
                     const double am = __hiloint2double(am_hi, 0);
-                    accM[r][t] = mfma(am, bwc[t], accM[r][t]);
-                    if constexpr (s < RPW) {  // the row's 16 pieces spread evenly over the step's MFMAs
+                    if constexpr (t < NTMB) {
+                        accM[r][t] = mfma(am, bwc[t], accM[r][t]);
+                    } else {
+                        accS[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, bsc, accS[r], 0, 0, 0);
+                    }
+                    if constexpr (s < RPW) {  // the row's pieces spread evenly over the step's MFMAs
                         constexpr int P0 = i * STAGE_PIECES / SLOTS, P1 = (i + 1) * STAGE_PIECES / SLOTS;
                         static_for<P1 - P0>([&](auto o_tag) {
                             stage_piece(tile + 1, lane, s_tag, std::integral_constant<int, P0 + decltype(o_tag)::value>{});
@@ -763,13 +786,15 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                         const int smp = 4 * (s + 1) + l4;
                         mwn = Msc[smp * 4 + (DW * wave) / 64];
 #pragma unroll
-                        for (int tt = 0; tt < NTM; ++tt) bwn[tt] = Ws[smp * WS + 16 * tt + l15];
+                        for (int tt = 0; tt < NTMB; ++tt) bwn[tt] = Ws[smp * WS + 16 * tt + l15];
+                        if constexpr (SPLIT) bsn = Ws[smp * WS + 16 * NTP + PADS + (lane & 3)];
                     }
                 });
                 if constexpr (s + 1 < 8) {
                     mwc = mwn;
 #pragma unroll
-                    for (int t = 0; t < NTM; ++t) bwc[t] = bwn[t];
+                    for (int t = 0; t < NTMB; ++t) bwc[t] = bwn[t];
+                    bsc = bsn;
                 }
             });
             stage_end(lane, (int)((tile + 1 - tile_begin) & 1));
@@ -931,13 +956,28 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 for (int t = 0; t < NTP; ++t) {
                     const int c = 16 * t + l15;
                     if (c < KP) out[L.S + (int64_t)dim * KP + c] = accM[r][t][q];
+                    if constexpr (SPLIT) {  // [w z | w] columns 0 .. PADS-1 sit behind vech(P) in the last tile
+                        if (t == NTP - 1 && c >= KP) {
+                            const int a = c - KP;
+                            if (a < K) out[L.U + (int64_t)dim * K + a] = accM[r][t][q];
+                            else if (a == K) out[L.totals + dim] = accM[r][t][q];
+                        }
+                    }
                 }
                 if (l15 < K) {
-                    out[L.U + (int64_t)dim * K + l15] = accM[r][NTP][q];
+                    if constexpr (!SPLIT) out[L.U + (int64_t)dim * K + l15] = accM[r][NTP][q];
                     out[L.cross + (int64_t)dim * K + l15] = accX[r][q];
                 } else if (l15 == K) {
-                    out[L.totals + dim] = accM[r][NTP][q];
+                    if constexpr (!SPLIT) out[L.totals + dim] = accM[r][NTP][q];
                     out[L.sumx + dim] = accX[r][q];
+                }
+            }
+            if constexpr (SPLIT) {  // 4x4x4 group: D lane = 16 i + 4 block + j
+                const int dim = DW * wave + 16 * r + 4 * ((lane >> 2) & 3) + (lane >> 4);
+                const int a = PADS + (lane & 3);  // index in [w z | w]
+                if (dim < d) {
+                    if (a < K) out[L.U + (int64_t)dim * K + a] = accS[r];
+                    else if (a == K) out[L.totals + dim] = accS[r];
                 }
             }
         }
