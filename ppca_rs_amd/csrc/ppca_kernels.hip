@@ -729,14 +729,27 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             //     requested one per k-step behind these MFMAs (a burst of all of them stalls the wave
             //     ~2.9k cycles on the memory queue: a CU drains ~10 B/cycle)
             PPCA_STAMP(6)
+            {
+                // operands of step s+1 are read from LDS before the MFMAs of step s issue (fenced: hipcc otherwise
+                // sinks the reads to their uses and waits on LDS in front of every step)
+                double bzb[2], axb[2][RT];
+                bzb[0] = Ws[l4 * WS + 16 * NTP + l15];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s < RPW) load_row(tile + 1, s);  // unconditional (clamped rows)
-                const int smp = 4 * s + l4;
-                const double bz = Ws[smp * WS + 16 * NTP + l15];
+                for (int r = 0; r < RT; ++r) axb[0][r] = Xs[l4 * XS + DW * wave + 16 * r + l15];
 #pragma unroll
-                for (int r = 0; r < RT; ++r)
-                    accX[r] = mfma(Xs[smp * XS + DW * wave + 16 * r + l15], bz, accX[r]);
+                for (int s = 0; s < 8; ++s) {
+                    if (s < RPW) load_row(tile + 1, s);  // unconditional (clamped rows)
+                    if (s + 1 < 8) {
+                        const int smp = 4 * (s + 1) + l4;
+                        bzb[(s + 1) & 1] = Ws[smp * WS + 16 * NTP + l15];
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) axb[(s + 1) & 1][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s & 1][r], bzb[s & 1], accX[r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __syncthreads();  // the x~ tile is free
             PPCA_STAMP(4)
