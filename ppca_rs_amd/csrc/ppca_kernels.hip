@@ -644,9 +644,12 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             post.solve([&](int a) { return g0[16 * NTP + a] + g1[16 * NTP + a]; }, z, quad, zz);
             PPCA_STAMP(9)
             double trpart = 0.0;
+            // llk / llks / states / smooth / extrapolate need z only: the posterior covariance (the M^-1 columns)
+            // is computed when somebody reads it -- covariances out, or the covariance diagonals
+            const bool need_cov = EM || p.covs != nullptr || (p.recon != nullptr && p.recon_mode >= 2);
 #pragma unroll
             for (int c = 0; c < K; ++c) {
-                if (column_owner(K, c, NW) != wave) continue;
+                if (column_owner(K, c, NW) != wave || !need_cov) continue;
                 if constexpr (EM) {
                     // P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439), weighted
                     trpart += post.minv_column(
@@ -870,41 +873,41 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     }
                 }
             }
-            // C/D map of v_mfma_f64_16x16x4: row (sample) = l4 + 4 r, column (dim) = l15: every store
-            // instruction writes four 128-byte runs.  Branch-free: the observed values of extrapolate are
-            // requested for all 32 elements first (clamped addresses), then everything is selected and stored
-            // (a load or `continue` inside the element loop puts a vmcnt(0) behind every single store).
-            const bool extra = p.recon_mode == 1, zero_obs = p.recon_mode == 3;
-            double xo[CT][2][4];
-            if (extra) {
-#pragma unroll
-                for (int c4 = 0; c4 < CT; ++c4) {
-                    const int j = 64 * wave + 16 * c4 + l15, jc = j < d ? j : d - 1;
-#pragma unroll
-                    for (int rt2 = 0; rt2 < 2; ++rt2)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int64_t row = tile * B + 16 * rt2 + l4 + 4 * r;
-                            xo[c4][rt2][r] = p.X[(row < n ? row : n - 1) * p.ldx + jc];  // bit-exact pass-through
-                        }
-                }
-            }
+            // C/D map of v_mfma_f64_16x16x4: row (sample) = l4 + 4 r, column (dim) = l15.  The results go through
+            // the x~ tile (free after P2 in the output passes) and leave as whole rows: per row and wave four
+            // 512-byte stores under a wave-uniform row test, the observed values of extrapolate re-read the same
+            // way (bit-exact pass-through).  (Storing straight from the accumulator layout put each 8-byte store
+            // in its own exec-masked branch with a vmcnt wait: up to 40x slower, depending on hipcc's mood.)
 #pragma unroll
             for (int c4 = 0; c4 < CT; ++c4) {
-                const int j = 64 * wave + 16 * c4 + l15;
                 const double add = dg ? s2 : muo[c4];
 #pragma unroll
                 for (int rt2 = 0; rt2 < 2; ++rt2)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * rt2 + l4 + 4 * r;
-                        const int64_t row = tile * B + i;
-                        const bool obs = (Msc[i * 4 + wave] >> (16 * c4 + l15)) & 1ull;
-                        double out = oacc[rt2][c4][r] + add;
-                        if (extra) out = obs ? xo[c4][rt2][r] : out;
-                        if (zero_obs) out = obs ? 0.0 : out;
-                        if (row < n && j < d) p.recon[row * (int64_t)d + j] = out;
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        Xs[(16 * rt2 + l4 + 4 * r) * XS + 64 * wave + 16 * c4 + l15] = oacc[rt2][c4][r] + add;
+            }
+            __syncthreads();
+            const bool extra = p.recon_mode == 1, zero_obs = p.recon_mode == 3;
+            for (int ri = wave; ri < B; ri += NW) {
+                const int64_t row = tile * B + ri;
+                if (row >= n) break;  // wave-uniform
+                double val[4], xin[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = 64 * q + lane;
+                    val[q] = Xs[ri * XS + j];
+                    xin[q] = extra ? p.X[row * p.ldx + (j < d ? j : d - 1)] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = 64 * q + lane;
+                    const bool obs = (Msc[ri * 4 + q] >> lane) & 1ull;
+                    double out = val[q];
+                    if (extra) out = obs ? xin[q] : out;
+                    if (zero_obs) out = obs ? 0.0 : out;
+                    if (j < d) p.recon[row * (int64_t)d + j] = out;
+                }
             }
         }
         __syncthreads();
