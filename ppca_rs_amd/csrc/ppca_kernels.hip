@@ -828,6 +828,26 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             static_assert(EM || NW == 4, "output pass: four waves x four dim tiles");
             constexpr int CT = 4;
             const bool dg = p.recon_mode >= 2;
+            // Loads and stores share one in-order counter (vmcnt): a load consumed after a store waits for that
+            // store to be acknowledged by memory.  So every load of this pass -- the observed values extrapolate
+            // passes through bit-exactly -- is issued HERE, before any store of the tile, and the stores at the
+            // end run back to back.
+            const bool extra = p.recon_mode == 1, zero_obs = p.recon_mode == 3;
+            constexpr int ROWS = B / NW;
+            double xin[ROWS][4];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xin[rr][q] = 0.0;
+            if (extra) {
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    const int64_t row = tile * B + wave + NW * rr;
+                    const double *xrow = p.X + (row < n ? row : n - 1) * p.ldx;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xin[rr][q] = xrow[64 * q + lane < d ? 64 * q + lane : d - 1];
+                }
+            }
             d4_t oacc[2][CT];
 #pragma unroll
             for (int rt2 = 0; rt2 < 2; ++rt2)
@@ -888,25 +908,19 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                         Xs[(16 * rt2 + l4 + 4 * r) * XS + 64 * wave + 16 * c4 + l15] = oacc[rt2][c4][r] + add;
             }
             __syncthreads();
-            const bool extra = p.recon_mode == 1, zero_obs = p.recon_mode == 3;
-            for (int ri = wave; ri < B; ri += NW) {
-                const int64_t row = tile * B + ri;
-                if (row >= n) break;  // wave-uniform
-                double val[4], xin[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = 64 * q + lane;
-                    val[q] = Xs[ri * XS + j];
-                    xin[q] = extra ? p.X[row * p.ldx + (j < d ? j : d - 1)] : 0.0;
-                }
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int ri = wave + NW * rr;
+                const int64_t row = tile * B + ri;
+                const bool row_ok = row < n;  // wave-uniform
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int j = 64 * q + lane;
                     const bool obs = (Msc[ri * 4 + q] >> lane) & 1ull;
-                    double out = val[q];
-                    if (extra) out = obs ? xin[q] : out;
+                    double out = Xs[ri * XS + j];
+                    if (extra) out = obs ? xin[rr][q] : out;
                     if (zero_obs) out = obs ? 0.0 : out;
-                    if (j < d) p.recon[row * (int64_t)d + j] = out;
+                    if (row_ok && j < d) p.recon[row * (int64_t)d + j] = out;
                 }
             }
         }
