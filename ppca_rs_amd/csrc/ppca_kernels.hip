@@ -658,10 +658,6 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     trpart += post.minv_column(c, [&](int a, int cc, double v) {
                         const double sv = s2 * v;
                         wrow[K + tri(a, cc)] = sv;  // post mode: W row = [z (K) | Sigma packed (K')]
-                        if (p.covs && row < n) {
-                            p.covs[row * K * K + a * K + cc] = sv;
-                            p.covs[row * K * K + cc * K + a] = sv;
-                        }
                     });
                 }
             }
@@ -693,10 +689,6 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 } else {
 #pragma unroll
                     for (int a = 0; a < K; ++a) wrow[a] = z[a];
-                    if (p.states && row < n) {
-#pragma unroll
-                        for (int a = 0; a < K; ++a) p.states[row * K + a] = z[a];
-                    }
                 }
                 if constexpr (EM) {
                     const double lk0 = sample_llk_nolog(xx, quad, inv_s2, lnsig, m, K);
@@ -726,6 +718,25 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         PPCA_STAMP(11)
         __syncthreads();
         PPCA_STAMP(2)
+        if constexpr (!EM) {
+            // InferredMasked outputs (src/python_bindings.rs:211-234): the tile's states (32 x k) and covariances
+            // (32 x k x k) are contiguous in the output arrays, so they are written from the W rows by the whole
+            // workgroup with consecutive lanes on consecutive addresses (not 8 bytes per lane 8 k^2 bytes apart)
+            if (p.states) {
+                for (int idx = tid; idx < B * K; idx += THREADS) {
+                    const int i = idx / K, a = idx - i * K;
+                    const int64_t row = tile * B + i;
+                    if (row < n) p.states[row * K + a] = Ws[i * WS + a];
+                }
+            }
+            if (p.covs) {
+                for (int idx = tid; idx < B * K * K; idx += THREADS) {
+                    const int i = idx / (K * K), rem = idx - i * (K * K), a = rem / K, c = rem - a * K;
+                    const int64_t row = tile * B + i;
+                    if (row < n) p.covs[row * (K * K) + rem] = Ws[i * WS + K + (a >= c ? tri(a, c) : tri(c, a))];
+                }
+            }
+        }
         if constexpr (EM) {
             // -------------------------------------------------------- P4
             // (a) cross/sumx += X~^T [wz | w]: the only reader of the x~ tile; the next tile's rows are

@@ -41,3 +41,10 @@ def cdiag(mode):
     _lib.check(L.ppca_covariance_diagonal(ctx.handle, ds._h, md.h, mode, C.byref(o)))
     L.ppca_dataset_free(o)
 timed("smoothed cov diagonal", lambda: cdiag(0), 16 * d)
+nn = min(n, 1_000_000)
+sub = ds._slice(0, nn)
+st, cv = np.empty((nn, k)), np.empty((nn, k, k))
+t0 = time.perf_counter(); _lib.check(L.ppca_infer(ctx.handle, sub._h, md.h, _lib.ptr(st), None)); t1 = time.perf_counter()
+_lib.check(L.ppca_infer(ctx.handle, sub._h, md.h, _lib.ptr(st), _lib.ptr(cv))); t2 = time.perf_counter()
+print(f"infer states only ({nn} rows, incl. D2H)      {1e3*(t1-t0):8.2f} ms")
+print(f"infer states + covariances (incl. D2H {cv.nbytes/1e6:.0f} MB) {1e3*(t2-t1):8.2f} ms")
