@@ -135,61 +135,71 @@ constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
 
 // qtab: [NTP][QS][4 k-chunks][64 lanes][16 bytes]; lane = 16 (dim/16 % 4) + (col % 16), byte = dim % 16
 // qscale: [64] dequantisation multipliers 2^(E_c - (7 QS - 2)).
-// Step 1 (one workgroup, thread = dim): column maxima -> qscale.
+// One workgroup per packed-column tile t (256 threads).  Step 1, thread = dim: maxima of the tile's 16 columns
+// (wave-level maximum first -- non-negative doubles order like their bit patterns -- then one LDS atomic per wave)
+// -> qscale.  Step 2, thread = (k-chunk, lane): 16 dims x one column, its 16 digits of every slice as one 16-byte
+// store per slice.  (Two launches before: a single-workgroup maximum over all 55 columns took 21 us per iteration.)
 template <int K>
-__global__ __launch_bounds__(256) void qmax_kernel(const double *model, int d, double *qscale) {
-    constexpr int NTP = Cfg<K>::NTP;
-    __shared__ unsigned long long cmax[16 * NTP];
-    const int j = threadIdx.x;
-    for (int c = j; c < 16 * NTP; c += 256) cmax[c] = 0ull;
+__global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, double *qscale, signed char *qtab) {
+    constexpr int KP = Cfg<K>::KP;
+    __shared__ unsigned long long cmax[16];
+    __shared__ double scale[16];
+    const int t = blockIdx.x, j = threadIdx.x;
+    if (j < 16) cmax[j] = 0ull;
     __syncthreads();
     double cj[K];
 #pragma unroll
     for (int a = 0; a < K; ++a) cj[a] = (j < d) ? model[MODEL_HDR + (int64_t)j * K + a] : 0.0;
+    double q[16];
 #pragma unroll
-    for (int a = 0; a < K; ++a)
+    for (int cc = 0; cc < 16; ++cc) {
+        const int c = 16 * t + cc;
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= c) ++a;
+        const int b = c - a * (a + 1) / 2;
+        double ca = 0.0, cb = 0.0;
 #pragma unroll
-        for (int b = 0; b <= a; ++b) {
-            double q = fabs(cj[a] * cj[b]);
-            if (!(q < 1.0e300)) q = 0.0;
-            // wave-level maximum first (non-negative doubles order like their bit patterns), then one
-            // LDS atomic per wave instead of 256 contending ones
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) q = fmax(q, __shfl_xor(q, o, 64));
-            if ((j & 63) == 0 && q > 0.0) atomicMax(&cmax[tri(a, b)], (unsigned long long)__double_as_longlong(q));
+        for (int u = 0; u < K; ++u) {  // (register arrays are indexed by compile-time constants only)
+            ca = (u == a) ? cj[u] : ca;
+            cb = (u == b) ? cj[u] : cb;
         }
+        q[cc] = (c < KP) ? fabs(ca * cb) : 0.0;
+        if (!(q[cc] < 1.0e300)) q[cc] = 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)  // sixteen independent butterflies per level: the shuffle latency overlaps
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) q[cc] = fmax(q[cc], __shfl_xor(q[cc], o, 64));
+    if ((j & 63) == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc)
+            if (q[cc] > 0.0) atomicMax(&cmax[cc], (unsigned long long)__double_as_longlong(q[cc]));
+    }
     __syncthreads();
-    if (j < 16 * NTP) {
+    if (j < 16) {
         int e = 0;
         const double mx = __longlong_as_double((long long)cmax[j]);
         if (mx > 0.0) (void)frexp(mx, &e);
-        qscale[j] = ldexp(1.0, e - (7 * QS - 2));
+        const double sc = ldexp(1.0, e - (7 * QS - 2));
+        scale[j] = sc;
+        qscale[16 * t + j] = sc;
     }
-}
-
-// Step 2: one thread per (column tile, slice-independent) 16-byte fragment row: thread -> (t, kc, lane),
-// i.e. 16 dims x one column; writes its 16 digits of every slice as one 16-byte store per slice.
-template <int K>
-__global__ __launch_bounds__(256) void qdigits_kernel(const double *model, int d, const double *qscale,
-                                                      signed char *qtab) {
-    constexpr int KP = Cfg<K>::KP, NTP = Cfg<K>::NTP;
-    const int idx = blockIdx.x * 256 + threadIdx.x;  // ((t * 4 + kc) * 64 + lane)
-    if (idx >= NTP * 4 * 64) return;
-    const int lane = idx & 63, kc = (idx >> 6) & 3, t = idx >> 8;
+    __syncthreads();
+    const int lane = j & 63, kc = j >> 6;
     const int c = 16 * t + (lane & 15);
     int a = 0;
     while ((a + 1) * (a + 2) / 2 <= c) ++a;
     const int b = c - a * (a + 1) / 2;
     const int j0 = 64 * kc + 16 * (lane >> 4);
     int ex = 0;
-    (void)frexp(qscale[c < 16 * NTP ? c : 0], &ex);  // qscale = 2^(E - (7 QS - 2)) = 0.5 * 2^(ex)
-    const int shift = -(ex - 1);                       // multiply by 2^(7 QS - 2 - E)
+    (void)frexp(scale[lane & 15], &ex);  // scale = 2^(E - (7 QS - 2)) = 0.5 * 2^(ex)
+    const int shift = -(ex - 1);         // multiply by 2^(7 QS - 2 - E)
     union { signed char b8[QS][16]; i4_t v[QS]; } dg;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
-        const int j = j0 + jj;
+        const int jd = j0 + jj;
         double q = 0.0;
-        if (c < KP && j < d) q = model[MODEL_HDR + (int64_t)j * K + a] * model[MODEL_HDR + (int64_t)j * K + b];
+        if (c < KP && jd < d) q = model[MODEL_HDR + (int64_t)jd * K + a] * model[MODEL_HDR + (int64_t)jd * K + b];
         if (!(fabs(q) < 1.0e300)) q = 0.0;
         long long I = llrint(ldexp(q, shift));  // |I| <= 2^(7 QS - 2)
 #pragma unroll
@@ -1250,8 +1260,7 @@ static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
     }
     if constexpr (GI8) {
         // slice table of the current model (device-side, no host sync): column maxima, then digits
-        hipLaunchKernelGGL((qmax_kernel<K>), dim3(1), dim3(256), 0, s, a.model, a.d, a.qscale);
-        hipLaunchKernelGGL((qdigits_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab);
+        hipLaunchKernelGGL((qprep_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab);
     }
     hipLaunchKernelGGL((pass_kernel<K, EM, NW, GI8>), dim3(grid), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
