@@ -328,6 +328,49 @@ def test_dump_load_both_containers(P):
         P.PPCAModel.load(m.dump("bincode")[:-5])
 
 
+@pytest.mark.parametrize("k", list(range(1, 11)))
+def test_fused_path_shape_sweep(P, oracle, k):
+    """Every state size of the fused kernel (each is its own instantiation: different tile counts, piece
+    schedules, 4x4x4 split only at k = 10) x ragged d and N, weights, all-masked rows: statistics buffer, llks,
+    posteriors and all four output passes against the oracle."""
+    from ppca_rs_amd import _lib
+
+    rng = np.random.default_rng(40 + k)
+    for d, n in ((256, 97), (255, 64), (200, 33), (64, 129), (max(k, 3), 31)):
+        assert _lib.lib().ppca_path_kind(d, k) == 1
+        x, _, _ = oracle.synth(n, d, k, 0.35, 900 + 10 * k + d)
+        x[n // 2] = np.nan
+        w = rng.uniform(0.25, 2.0, n)
+        c, mu, s = 0.5 * rng.standard_normal((d, k)), 0.2 * rng.standard_normal(d), 0.6
+        ds, m = P.Dataset(x, w), P.PPCAModel(s, c, mu)
+        L = _lib.lib().ppca_stats_len(d, k)
+        got = np.empty(L)
+        _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
+        want = oracle.stats(x, s, c, mu, w)
+        kp = k * (k + 1) // 2
+        bounds = [0, d * k, d * k + d * kp, 2 * d * k + d * kp, 2 * d * k + d * kp + d, 2 * d * k + d * kp + 2 * d, L]
+        for name, a, b in zip(["cross", "S", "U", "sumx", "totals", "scalars"], bounds[:-1], bounds[1:]):
+            assert _rel(got[a:b], want[a:b]) < 1e-9, (name, d, n)
+        # the same, unweighted (the other llk path of the EM pass: one logarithm per kernel)
+        dsu = P.Dataset(x)
+        _lib.check(_lib.lib().ppca_stats_raw(dsu._ctx.handle, dsu._h, m._device(dsu._ctx).h, _lib.ptr(got)))
+        want = oracle.stats(x, s, c, mu)
+        assert _rel(got[bounds[-2]:], want[bounds[-2]:]) < 1e-9 and _rel(got[:bounds[-2]], want[:bounds[-2]]) < 1e-9
+        assert _rel(m.llks(ds), oracle.llks(x, s, c, mu)) < 1e-10
+        st, cv = oracle.infer(x, s, c, mu)
+        inf = m.infer(ds)
+        assert _rel(inf.states(), st) < 1e-8 and _rel(np.array(inf.covariances()), cv) < 1e-8
+        assert _rel(m.smooth(ds).numpy(), oracle.reconstruct(x, s, c, mu, "smooth")) < 1e-9
+        ex = m.extrapolate(ds).numpy()
+        assert _rel(ex, oracle.reconstruct(x, s, c, mu, "extrapolate")) < 1e-9
+        assert np.array_equal(ex[np.isfinite(x)], x[np.isfinite(x)])
+        assert _rel(inf.smoothed_covariances_diagonal(m).numpy(), oracle.covariance_diagonal(x, s, c, mu, "smooth")) < 1e-8
+        for mode, name in ((0, "smooth"), (1, "extrapolate")):
+            h = C.c_void_p()
+            _lib.check(_lib.lib().ppca_covariance_diagonal(ds._ctx.handle, ds._h, m._device(ds._ctx).h, mode, C.byref(h)))
+            assert _rel(P.Dataset._wrap(h, ds._ctx).numpy(), oracle.covariance_diagonal(x, s, c, mu, name)) < 1e-8
+
+
 def test_full_size_properties(P):
     """BASELINE config 2 at full size (N = 1M, d = 256, k = 10, 30 % masked): size-independent
     properties -- EM monotonicity, shard additivity of the statistics (the multi-GPU invariant),
