@@ -51,7 +51,7 @@ struct Cfg {
     // once-per-tile values in scratch and reloads them with an exposed vmcnt(0)):
     // sq[NW <= 8 waves][B] | dev[B] | llk[B] | sumw[B] | nonempty[B] | det mantissa[B] | det exponent[B]
     static constexpr int OFF_L = OFF_S + 2 * B;
-    static constexpr int LDS_DOUBLES = OFF_L + 14 * B;
+    static constexpr int LDS_DOUBLES = OFF_L + 22 * B;  // (sq has two slots per solver sample when the waves pair lanes)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -308,9 +308,12 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // (mantissa, exponent) product and takes ONE logarithm at the end of the kernel (a per-tile fp64 log
     // cost 2.2k of ~35k cycles per tile: its constants live in scratch at this register pressure)
     double *scl = sm + cfg::OFF_L;
-    constexpr int L_DEV = NW * B, L_LLK = (NW + 1) * B, L_W = (NW + 2) * B, L_NE = (NW + 3) * B, L_PM = (NW + 4) * B,
-                  L_PX = (NW + 5) * B;
-    for (int idx = tid; idx < (NW + 6) * B; idx += THREADS) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
+    // PAIRS: the M^-1 columns are computed two at a time, by lane i (column 2p) and lane i + 32 (column 2p + 1)
+    constexpr bool PAIRS = EM && NW == 4 && K >= 2;
+    constexpr int SQW = PAIRS ? 2 * B : B;  // sq slots per wave
+    constexpr int L_DEV = NW * SQW, L_LLK = L_DEV + B, L_W = L_DEV + 2 * B, L_NE = L_DEV + 3 * B, L_PM = L_DEV + 4 * B,
+                  L_PX = L_DEV + 5 * B;
+    for (int idx = tid; idx < L_DEV + 6 * B; idx += THREADS) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
     const double inv_s2 = 1.0 / s2;
 
     const int64_t ntiles = (n + B - 1) / B;
@@ -635,8 +638,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         // ------------------------------------------------------------ P3
         // Every wave factors every sample (lane = sample, redundantly, in parallel) and the waves
         // share the independent columns of M^-1; wave 0 also owns z, llk and the scalars.
-        if (lane < B) {
-            const int i = lane;
+        if (PAIRS || lane < B) {
+            const int i = lane & (B - 1);
+            const int hi = PAIRS ? lane >> 5 : 0;  // which column of a pair this half of the wave solves for
             const int64_t row = tile * B + i;
             const double *g0 = Gp + i * GS;
             const double *g1 = g0 + B * GS;
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             const int m = mcnt[i];
             double *wrow = Ws + i * WS;
             double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;  // this tile's terms
-            const double sq_run = scl[wave * B + i];
+            const double sq_run = scl[wave * SQW + (PAIRS ? lane : i)];
             Posterior<K> post;
             double pm;
             int pe;
@@ -657,8 +661,21 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             // llk / llks / states / smooth / extrapolate need z only: the posterior covariance (the M^-1 columns)
             // is computed when somebody reads it -- covariances out, or the covariance diagonals
             const bool need_cov = EM || p.covs != nullptr || (p.recon != nullptr && p.recon_mode >= 2);
+            if constexpr (PAIRS) {
 #pragma unroll
-            for (int c = 0; c < K; ++c) {
+                for (int pp = 0; pp < (K + 1) / 2; ++pp) {
+                    if (pair_owner(K, pp, NW) != wave) continue;
+                    const int c0 = 2 * pp;
+                    const double zc = (hi && c0 + 1 < K) ? z[c0 + 1 < K ? c0 + 1 : c0] : z[c0];
+                    // P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439), weighted;
+                    // tri(t, c0) + 1 = tri(t, c0 + 1)
+                    trpart += post.minv_column_pair(c0, hi, [&](int t, double v, bool ok) {
+                        if (ok && c0 + hi < K) wrow[tri(t, c0) + hi] = wgt * (z[t] * zc + s2 * v);
+                    });
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < (PAIRS ? 0 : K); ++c) {
                 if (column_owner(K, c, NW) != wave || !need_cov) continue;
                 if constexpr (EM) {
                     // P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439), weighted
@@ -677,7 +694,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 // share of its columns.  All-masked samples are filtered out of the noise sums (:333).
                 if (m > 0) sc_sq -= wgt * s2 * s2 * trpart;
             }
-            if (wave == 0) {
+            if (wave == 0 && hi == 0) {
                 const double xx = EM ? 0.0 : xxs[i];  // EM: the |x~|^2 terms are added once, in the epilogue
                 // running sums: requested at the top of the block, needed at its end
                 const double run_dev = scl[L_DEV + i], run_llk = scl[L_LLK + i], run_w = scl[L_W + i], run_ne = scl[L_NE + i];
@@ -723,7 +740,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 scl[L_W + i] = run_w + sc_w;
                 scl[L_NE + i] = run_ne + sc_ne;
             }
-            if constexpr (EM) scl[wave * B + i] = sq_run + sc_sq;
+            if constexpr (EM) scl[wave * SQW + (PAIRS ? lane : i)] = sq_run + sc_sq;
         }
         PPCA_STAMP(11)
         __syncthreads();
@@ -956,7 +973,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // ------------------------------------------------------------ epilogue
     // scalars: deterministic reduction over the 32 solver lanes of each wave, then over the waves
     {
-        const double sq_w = wave_sum(lane < B ? scl[wave * B + lane] : 0.0);
+        const double sq_w = wave_sum(lane < SQW ? scl[wave * SQW + lane] : 0.0);
         const double xx_w = wave_sum(xx_run);
         if (lane == 0) {  // xxs is free after the last tile
             xxs[wave] = sq_w;

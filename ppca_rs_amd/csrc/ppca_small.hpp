@@ -160,6 +160,37 @@ struct Posterior {
         sched_fence();
         return u[c];
     }
+
+    // Two columns at once, one per half of the wave (hi = 0: column c0, hi = 1: column c0 + 1), with the loop
+    // bounds of c0: a solver lane pair (lane, lane + 32) holds the same factor, so the half-empty wave of the
+    // 32-sample tile does the columns' work two at a time.  st(t, v, ok): entry (t, c0 + hi) = v when ok.
+    template <class Store>
+    PPCA_HD double minv_column_pair(int c0, int hi, Store st) const {
+        double u[K];
+#pragma unroll
+        for (int a = 0; a < K; ++a) u[a] = (a == c0 + hi) ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            if (t < c0) continue;
+            u[t] *= L[tri(t, t)];
+#pragma unroll
+            for (int a = t + 1; a < K; ++a) u[a] -= L[tri(a, t)] * u[t];
+        }
+        double diag = 0.0;
+#pragma unroll
+        for (int t = K - 1; t >= 0; --t) {
+            if (t < c0) continue;
+            u[t] *= L[tri(t, t)];
+            st(t, u[t], t > c0 || hi == 0);
+            if (t == c0 + 1) diag = hi ? u[t] : diag;
+            if (t == c0) diag = hi ? diag : u[t];
+#pragma unroll
+            for (int a = 0; a < t; ++a)
+                if (a >= c0) u[a] -= L[tri(t, a)] * u[t];
+        }
+        sched_fence();
+        return diag;  // (M^-1) at (c0 + hi, c0 + hi); 0 for the unpaired half of an odd last column
+    }
 };
 
 // Which of nw workers owns column c of M^-1: greedy balance of the column costs -- (K - c)^2 multiply-adds
@@ -176,6 +207,23 @@ PPCA_HD constexpr int column_owner(int K, int c, int nw) {
         for (int w = 1; w < nw; ++w)
             if (load[w] < load[own]) own = w;
         load[own] += (K - cc) * (K - cc) + 4 * (K - cc);
+    }
+    return own;
+}
+
+// The same for column PAIRS (2p, 2p + 1), each costing what its first column costs (Posterior::minv_column_pair).
+PPCA_HD constexpr int pair_owner(int K, int p, int nw) {
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int total = 0;
+    for (int cc = 0; cc < K; ++cc) total += (K - cc) * (K - cc) + 4 * (K - cc);
+    load[0] = total / (nw + 1);  // worker 0's own extras, in the same units
+    int own = 0;
+    for (int pp = 0; pp <= p; ++pp) {
+        own = 0;
+        for (int w = 1; w < nw; ++w)
+            if (load[w] < load[own]) own = w;
+        const int c0 = 2 * pp;
+        load[own] += (K - c0) * (K - c0) + 4 * (K - c0);
     }
     return own;
 }
