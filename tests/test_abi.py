@@ -67,3 +67,16 @@ def test_compiled_host_example_builds_and_links():
     assert os.path.exists(exe)
     needed = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
     assert "libppca_hip.so" in needed and "libtorch" not in needed and "python" not in needed.lower()
+
+
+def test_drop_in_package_exports_the_reference_names():
+    """`import ppca_rs` must offer the reference's classes (python/ppca_rs/__init__.py, .pyi)."""
+    import ppca_rs
+
+    for name in ["Dataset", "DatasetChunks", "Prior", "PPCAModel", "InferredMasked", "PosteriorSampler", "PPCAMix",
+                 "InferredMaskedMix", "PosteriorSamplerMix", "PPCATrainer", "PPCAMixTrainer", "TrainMetrics",
+                 "DataFrameAdapter", "DataFrameAdapterDescription", "__version__"]:
+        assert hasattr(ppca_rs, name), name
+    import ppca_rs_amd
+
+    assert ppca_rs.PPCAModel is ppca_rs_amd.PPCAModel
