@@ -371,6 +371,69 @@ def test_fused_path_shape_sweep(P, oracle, k):
             assert _rel(P.Dataset._wrap(h, ds._ctx).numpy(), oracle.covariance_diagonal(x, s, c, mu, name)) < 1e-8
 
 
+def test_reference_usage_patterns():
+    """The call patterns of the reference's own examples (examples/*.py: keyword construction, np.matrix and
+    transposed inputs, row or column means, positional mask probability, the `ppca_rs.ppca_rs` submodule, pickling,
+    priors, the mixture trainer, a k = 16 model on the generic path) run unchanged against this package."""
+    import pickle
+
+    import ppca_rs
+    from ppca_rs import Dataset, PPCAMix, PPCAMixTrainer, Prior
+    from ppca_rs.ppca_rs import PPCAModel
+
+    real = PPCAModel(transform=np.array([[1, 1], [0, 1], [0, 1]], dtype="float64"), isotropic_noise=0.1,
+                     mean=np.array([[0], [1], [0]], dtype="float64"))
+    sample = real.sample(100, mask_prob=0.2)
+    model = PPCAModel.init(2, sample)
+    llks = []
+    for _ in range(30):
+        llks.append(model.llk(sample))
+        model = model.iterate(sample)
+    assert all(b >= a - 1e-9 * abs(a) for a, b in zip(llks, llks[1:])) and len(sample) == 100
+    model = model.to_canonical()
+    assert "PPCAModel" in repr(model) and model.singular_values.shape == (2,)
+    sd = model.infer(sample).smoothed_covariances_diagonal(model).numpy() ** 0.5
+    assert sd.shape == (100, 3) and np.all(np.isfinite(sd))
+    # empty dimensions, matrix input, weights keyword
+    ds = Dataset(np.matrix([[1.0, 1.0, np.nan], [1.0, 1.0, np.nan]], dtype="float64"), weights=np.array([1.0, 2.0]))
+    assert ds.empty_dimensions() == [2]
+    # pickling a model built from a transposed matrix and a row mean
+    m2 = PPCAModel(transform=np.matrix([[1, 1, 0], [1, 0, 1]], dtype="float64").T, isotropic_noise=0.1,
+                   mean=np.array([[0, 1, 0]], dtype="float64"))
+    de = pickle.loads(pickle.dumps(m2))
+    assert repr(de) == repr(m2) and np.array_equal(de.transform, m2.transform)
+    # priors
+    prior = (Prior().with_isotropic_noise_prior(100.0, 100.0)
+             .with_mean_prior(np.array([1.0, 0.0, 1.0], dtype="float64"), 0.0001 * np.eye(3, dtype="float64").T))
+    s3 = m2.sample(100, mask_prob=0.2)
+    pm = PPCAModel.init(2, s3)
+    for _ in range(20):
+        pm = pm.iterate_with_prior(s3, prior)
+    assert np.abs(pm.to_canonical().mean - np.array([1.0, 0.0, 1.0])).max() < 0.05  # the tight mean prior wins
+    # mixture: sample, train for several model counts, inference outputs
+    mix = PPCAMix([PPCAModel(transform=np.matrix([[1, 0, 0], [0, 0, 1]], dtype="float64").T, isotropic_noise=0.1,
+                             mean=np.array([[1, 1, 1]], dtype="float64").T),
+                   PPCAModel(transform=np.matrix([[1, 1, 0], [1, 0, 1]], dtype="float64").T, isotropic_noise=0.1,
+                             mean=np.array([[0, 1, 0]], dtype="float64").T)], log_weights=np.log([0.33333, 0.66667]))
+    ms = mix.sample(100, 0.1)
+    fitted = None
+    for nm in (1, 2, 3):
+        fitted = PPCAMixTrainer(ms).train(n_models=nm, state_size=2, n_iters=10, quiet=True)
+    assert fitted.smooth(ms).numpy().shape == (100, 3) and fitted.extrapolate(ms).numpy().shape == (100, 3)
+    assert fitted.infer(ms).posteriors().shape == (100, 3)
+    # a 200 x 16 model (generic pipeline)
+    big = PPCAModel(transform=np.matrix(np.random.default_rng(0).binomial(1.0, 0.1, size=(200, 16)), dtype="float64"),
+                    isotropic_noise=0.1, mean=np.zeros((200, 1), dtype="float64"))
+    bs = big.sample(20_000, 0.2)
+    bm = PPCAModel.init(16, bs)
+    vals = []
+    for _ in range(4):
+        vals.append(bm.llk(bs) / len(bs))
+        bm = bm.iterate(bs)
+    assert all(b >= a for a, b in zip(vals, vals[1:]))
+    assert ppca_rs.__version__
+
+
 def test_full_size_properties(P):
     """BASELINE config 2 at full size (N = 1M, d = 256, k = 10, 30 % masked): size-independent
     properties -- EM monotonicity, shard additivity of the statistics (the multi-GPU invariant),
