@@ -210,6 +210,18 @@ int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models_
 int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
                  int32_t n_models, double *total_host, double *per_sample_host, double *log_posteriors_host);
 
+/* Building blocks of the sample-SHARDED mixture step (one process per GPU; the caller owns the collectives):
+ * ppca_mix_responsibilities_dev: u[c][i] = ln w_i + log r_ic (mix.rs:283-309; -inf for w_i <= 0) into u_dev
+ *   (n_models x n, component-major) and the per-sample mixture llk (:137-149) into lse_dev (nullable);
+ * ppca_vector_max_dev: max_i v_i skipping NaNs (:312-317); ppca_vector_exp_shift_dev: out_i = exp(v_i - shift)
+ *   (:320-323) -- the per-component sample weights once the maximum over ALL shards is known;
+ * ppca_vector_sum_dev: sum_i v_i (w_i) (:324-325 and the llk total). */
+int ppca_mix_responsibilities_dev(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
+                                  int32_t n_models, double *u_dev, double *lse_dev);
+int ppca_vector_max_dev(ppca_ctx *ctx, const double *v_dev, int64_t n, double *max_host);
+int ppca_vector_exp_shift_dev(ppca_ctx *ctx, const double *v_dev, double shift, int64_t n, double *out_dev);
+int ppca_vector_sum_dev(ppca_ctx *ctx, const double *v_dev, const double *w_dev, int64_t n, double *sum_host);
+
 /* PPCAMix::smooth / extrapolate (mix.rs:245-265, through InferredMaskedMix::smoothed :404-412 and
  * ::extrapolated :414-423) and the diagonal covariances around the mixture mean
  * (smoothed_covariance_diagonal :447-461, extrapolated_covariance_diagonal :489-505): posterior-weighted

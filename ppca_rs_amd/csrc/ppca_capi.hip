@@ -990,6 +990,53 @@ extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *con
     return PPCA_OK;
 }
 
+// ---- building blocks of the SHARDED mixture step (one process per GPU; ppca_rs_amd/distributed.py::ShardedMixEM)
+extern "C" int ppca_mix_responsibilities_dev(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models,
+                                             const double *log_weights, int32_t n_models, double *u_dev, double *lse_dev) {
+    if (!ctx || !log_weights || !u_dev) return fail(PPCA_ERR_INVALID, "null argument");
+    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
+    if (int rc = mix_check(ds, models, n_models)) return rc;
+    if (int rc = use_device(ctx)) return rc;
+    const int64_t n = ds->n;
+    if (n == 0) return PPCA_OK;
+    BufRef llk, u, lse;
+    if (int rc = mix_posteriors(ctx, ds, models, log_weights, n_models, llk, u, lse, nullptr)) return rc;
+    HIP_TRY(hipMemcpyAsync(u_dev, u->p, sizeof(double) * (size_t)n_models * n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (lse_dev) HIP_TRY(hipMemcpyAsync(lse_dev, lse->p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
+extern "C" int ppca_vector_max_dev(ppca_ctx *ctx, const double *v_dev, int64_t n, double *max_host) {
+    if (!ctx || !v_dev || !max_host) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = use_device(ctx)) return rc;
+    double *work = static_cast<double *>(ctx->work->p);
+    HIP_TRY(launch_reduce_max(v_dev, n, work + 1025, work, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(max_host, work + 1025, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
+extern "C" int ppca_vector_sum_dev(ppca_ctx *ctx, const double *v_dev, const double *w_dev, int64_t n, double *sum_host) {
+    if (!ctx || !v_dev || !sum_host) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = use_device(ctx)) return rc;
+    double *work = static_cast<double *>(ctx->work->p);
+    HIP_TRY(launch_reduce_sum(v_dev, w_dev, n, work + 1026, work, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(sum_host, work + 1026, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
+extern "C" int ppca_vector_exp_shift_dev(ppca_ctx *ctx, const double *v_dev, double shift, int64_t n, double *out_dev) {
+    if (!ctx || !v_dev || !out_dev) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = use_device(ctx)) return rc;
+    double *work = static_cast<double *>(ctx->work->p);
+    HIP_TRY(hipMemcpyAsync(work + 1025, &shift, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(launch_exp_shift(v_dev, work + 1025, n, out_dev, ctx->stream));
+    return PPCA_OK;
+}
+
 extern "C" int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
                                     int32_t n_models, int32_t mode, ppca_dataset **out) {
     if (!ctx || !log_weights || !out) return fail(PPCA_ERR_INVALID, "null argument");

@@ -122,3 +122,129 @@ class ShardedEM:
         """Detach the library from the torch stream (before the stream object dies)."""
         self.stream.synchronize()
         self.ctx.set_stream(None)
+
+
+# --------------------------------------------------------------------------- sharded mixture (BASELINE config 5)
+class _DeviceMixBackend:
+    """The per-shard pieces of one mixture EM step on this rank's GPU, through the C-ABI."""
+
+    def __init__(self, shard: Dataset, models, prior):
+        import torch
+
+        self.torch, self.shard, self.ctx, self.prior = torch, shard, shard._ctx, prior
+        self.d, self.k, self.nm = models[0].output_size, models[0].state_size, len(models)
+        self.cur = [m._device(self.ctx) for m in models]
+        self._keep_models = list(models)
+        self.n = len(shard)
+        self.L = stats_len(self.d, self.k)
+        self.u = torch.empty(max(self.nm * self.n, 1), dtype=torch.float64, device="cuda")
+        self.lse = torch.empty(max(self.n, 1), dtype=torch.float64, device="cuda")
+        self.wc = torch.empty(max(self.n, 1), dtype=torch.float64, device="cuda")
+        self.stats = torch.zeros(self.nm * self.L, dtype=torch.float64, device="cuda")
+        self._pref, self._keep = _prior_ref(prior)
+
+    def _arr(self):
+        return (C.c_void_p * self.nm)(*[m.h for m in self.cur])
+
+    def responsibilities(self, log_weights: np.ndarray) -> float:
+        """u[c][i] = ln w_i + log r_ic on the device; returns this shard's share of the mixture llk."""
+        if self.n == 0:
+            return 0.0
+        check(lib().ppca_mix_responsibilities_dev(self.ctx.handle, self.shard._h, self._arr(), ptr(log_weights), self.nm,
+                                                  C.c_void_p(self.u.data_ptr()), C.c_void_p(self.lse.data_ptr())))
+        tot = C.c_double(0.0)
+        wdev = lib().ppca_dataset_device_weights(self.shard._h)
+        check(lib().ppca_vector_sum_dev(self.ctx.handle, C.c_void_p(self.lse.data_ptr()), C.c_void_p(wdev) if wdev else None,
+                                        self.n, C.byref(tot)))
+        return tot.value
+
+    def local_max(self, c: int) -> float:
+        if self.n == 0:
+            return -np.inf
+        mx = C.c_double(0.0)
+        check(lib().ppca_vector_max_dev(self.ctx.handle, C.c_void_p(self.u.data_ptr() + 8 * c * self.n), self.n, C.byref(mx)))
+        return mx.value
+
+    def accumulate(self, c: int, shift: float):
+        """weights exp(u_c - shift), their sum, and the component's weighted statistics (device tensor view)."""
+        view = self.stats[c * self.L:(c + 1) * self.L]
+        if self.n == 0:
+            view.zero_()
+            return 0.0, view
+        check(lib().ppca_vector_exp_shift_dev(self.ctx.handle, C.c_void_p(self.u.data_ptr() + 8 * c * self.n), shift, self.n,
+                                              C.c_void_p(self.wc.data_ptr())))
+        s = C.c_double(0.0)
+        check(lib().ppca_vector_sum_dev(self.ctx.handle, C.c_void_p(self.wc.data_ptr()), None, self.n, C.byref(s)))
+        h = C.c_void_p()
+        check(lib().ppca_dataset_with_weights(self.shard._h, None, C.c_void_p(self.wc.data_ptr()), C.byref(h)))
+        try:
+            check(lib().ppca_em_accumulate(self.ctx.handle, h, self.cur[c].h, C.c_void_p(view.data_ptr())))
+            self.ctx.synchronize()
+        finally:
+            lib().ppca_dataset_free(h)
+        return s.value, view
+
+    def pack(self, extras: np.ndarray):
+        return self.torch.cat([self.stats, self.torch.from_numpy(extras).to("cuda")])
+
+    def unpack_extras(self, packed, count: int) -> np.ndarray:
+        return packed[-count:].cpu().numpy()
+
+    def finalize(self, c: int, packed) -> None:
+        h = C.c_void_p()
+        check(lib().ppca_model_alloc(self.ctx.handle, self.d, self.k, C.byref(h)))
+        new = _DevModel(h)
+        check(lib().ppca_em_finalize(self.ctx.handle, self.cur[c].h, C.c_void_p(packed.data_ptr() + 8 * c * self.L), self._pref, new.h))
+        self.cur[c] = new
+
+    def max_tensor(self, values):
+        return self.torch.tensor(values, dtype=self.torch.float64, device="cuda")
+
+    def models(self):
+        return [PPCAModel._from_device(m, self.ctx, self.d, self.k) for m in self.cur]
+
+
+class ShardedMixEM:
+    """PPCAMix::iterate_with_prior (mix.rs:281-337) over row shards, one process per GPU.  Per step: local
+    responsibilities; all-reduce(MAX) of the K per-component maxima of ln w_i + log r_ic (:312-317 take the maximum
+    over ALL samples); per component the weights exp(. - max), their sum and the weighted statistics; ONE
+    all-reduce(SUM) of [K statistic buffers | K weight sums | llk]; identical finalisation and new log-weights
+    (:335) on every rank.  `backend` supplies the per-shard pieces (default: this rank's GPU through the C-ABI)."""
+
+    def __init__(self, shard, start, prior: Optional[Prior] = None, group=None, backend=None):
+        self.group = group
+        self.log_weights = np.array(start.log_weights, dtype=np.float64)
+        self.nm = len(start.models)
+        self.backend = backend or _DeviceMixBackend(shard, start.models, prior)
+
+    def step(self) -> float:
+        """One EM step; returns the mixture log-likelihood of the input mixture over ALL shards."""
+        import torch.distributed as dist
+
+        be, nm = self.backend, self.nm
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        llk_local = be.responsibilities(self.log_weights)
+        mx = be.max_tensor([be.local_max(c) for c in range(nm)])
+        if multi:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        mx = np.asarray(mx.cpu().numpy(), dtype=np.float64)
+        shifts = np.where(np.isfinite(mx), mx, 0.0)
+        sums = np.zeros(nm)
+        for c in range(nm):
+            sums[c], _ = be.accumulate(c, float(shifts[c]))
+        packed = be.pack(np.concatenate([sums, [llk_local]]))
+        if multi:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+        extras = be.unpack_extras(packed, nm + 1)
+        for c in range(nm):
+            be.finalize(c, packed)
+        with np.errstate(divide="ignore"):
+            logsum = np.log(extras[:nm]) + shifts
+        m = logsum.max()
+        self.log_weights = logsum - m - np.log(np.exp(logsum - m).sum())  # robust_log_softmax, mix.rs:14-18
+        return float(extras[nm])
+
+    def mixture(self):
+        from .api import PPCAMix
+
+        return PPCAMix(self.backend.models(), self.log_weights)

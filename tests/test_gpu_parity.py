@@ -546,3 +546,18 @@ def test_two_ranks_on_one_gpu_match_single_rank(P, tmp_path):
     assert abs(a["sigma"] - b["sigma"]) < 1e-10 * a["sigma"]
     assert _rel(b["transform"], a["transform"]) < 1e-9 and _rel(b["mean"], a["mean"]) < 1e-9
     assert abs(a["llk"] - b["llk"]) < 1e-10 * abs(a["llk"])
+
+
+def test_sharded_mixture_two_ranks_on_one_gpu():
+    """BASELINE config 5's multi-GPU path (ShardedMixEM: all-reduce MAX of the component maxima, one all-reduce SUM
+    of K statistic buffers + weight sums + llk) with two gloo ranks sharing this GPU, against the single-process
+    PPCAMix.iterate on the whole dataset."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "tools", "mix_sharded_check.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "sharded mixture OK" in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])

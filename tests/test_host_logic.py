@@ -279,3 +279,113 @@ def test_property_sharded_finalisation_equals_whole(oracle, hiplib):
         assert np.allclose(new.transform, c1, rtol=1e-6, atol=1e-8) and np.allclose(new.mean, m1, rtol=1e-7, atol=1e-9)
 
     run()
+
+
+class _OracleMixBackend:
+    """CPU stand-in for the per-shard pieces of ShardedMixEM (the device backend runs them on the GPU): the oracle
+    computes responsibilities and weighted statistics of this rank's rows; finalisation is the product's host
+    finalisation.  Exercises the collective logic (MAX of maxima, shifted weights, ONE SUM, log-weights)."""
+
+    def __init__(self, oracle, x, w, sig, cs, ms):
+        import torch
+
+        self.o, self.x, self.w, self.torch = oracle, x, w, torch
+        self.sig, self.cs, self.ms = np.array(sig, float), np.array(cs, float), np.array(ms, float)
+        self.nm, self.d, self.k = self.cs.shape
+        from ppca_rs_amd.distributed import stats_len
+
+        self.L = stats_len(self.d, self.k)
+
+    def responsibilities(self, lw):
+        lp = self.o.mix_infer_cluster(self.x, self.sig, self.cs, self.ms, lw)
+        with np.errstate(divide="ignore"):
+            self.u = (np.log(np.where(self.w > 0, self.w, 0.0))[:, None] + lp).T.copy()  # mix.rs:304-309
+        return float((self.o.mix_llks(self.x, self.sig, self.cs, self.ms, lw) * self.w).sum())
+
+    def local_max(self, c):
+        return float(np.nanmax(self.u[c])) if self.u.shape[1] else -np.inf
+
+    def accumulate(self, c, shift):
+        wc = np.exp(self.u[c] - shift)
+        self._stats = getattr(self, "_stats", np.zeros(self.nm * self.L))
+        self._stats[c * self.L:(c + 1) * self.L] = self.o.stats(self.x, self.sig[c], self.cs[c], self.ms[c], wc)
+        return float(wc.sum()), None
+
+    def pack(self, extras):
+        return self.torch.from_numpy(np.concatenate([self._stats, extras]))
+
+    def unpack_extras(self, packed, count):
+        return packed[-count:].numpy()
+
+    def finalize(self, c, packed):
+        from ppca_rs_amd import PPCAModel
+        from ppca_rs_amd.distributed import finalize_host
+
+        new = finalize_host(PPCAModel(self.sig[c], self.cs[c], self.ms[c]), packed[c * self.L:(c + 1) * self.L].numpy())
+        self.sig[c], self.cs[c], self.ms[c] = new.isotropic_noise, new.transform, new.mean
+
+    def max_tensor(self, values):
+        return self.torch.tensor(values, dtype=self.torch.float64)
+
+    def models(self):
+        from ppca_rs_amd import PPCAModel
+
+        return [PPCAModel(self.sig[c], self.cs[c], self.ms[c]) for c in range(self.nm)]
+
+
+def _mix_case(oracle):
+    rng = np.random.default_rng(21)
+    d, k, nm = 10, 2, 3
+    x = np.concatenate([oracle.synth(70, d, k, 0.3, 300 + c, mean_scale=2.5)[0] for c in range(nm)])
+    rng.shuffle(x)
+    w = rng.uniform(0.5, 2.0, x.shape[0])
+    return x, w, np.array([1.0, 0.8, 1.2]), rng.standard_normal((nm, d, k)), rng.standard_normal((nm, d)), np.log([0.2, 0.5, 0.3])
+
+
+def _mix_worker(rank, world, port, queue):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from oracle import ppca_oracle as o
+    from ppca_rs_amd import PPCAMix, PPCAModel
+    from ppca_rs_amd.distributed import ShardedMixEM, shard_bounds
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, w, sig, cs, ms, lw = _mix_case(o)
+    a, b = shard_bounds(x.shape[0], world, rank)
+    start = PPCAMix([PPCAModel(sig[c], cs[c], ms[c]) for c in range(3)], lw)
+    em = ShardedMixEM(None, start, backend=_OracleMixBackend(o, x[a:b], w[a:b], sig, cs, ms))
+    llks = [em.step() for _ in range(3)]
+    be = em.backend
+    queue.put((rank, be.sig.copy(), be.cs.copy(), be.ms.copy(), em.log_weights.copy(), llks))
+    dist.destroy_process_group()
+
+
+def test_sharded_mixture_world_size_2_gloo(oracle, hiplib):
+    """BASELINE config 5's N > 1 path on CPU: two gloo ranks, each holding half the rows, against the oracle's
+    mixture iteration over the whole dataset (mix.rs:281-337)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mix_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    x, w, sig, cs, ms, lw = _mix_case(oracle)
+    want_llk = []
+    for _ in range(3):
+        want_llk.append(float((oracle.mix_llks(x, sig, cs, ms, lw) * w).sum()))
+        sig, cs, ms, lw = oracle.mix_iterate(x, sig, cs, ms, lw, w)
+    for _, s2, c2, m2, lw2, llks in res:
+        np.testing.assert_allclose(llks, want_llk, rtol=1e-10)
+        np.testing.assert_allclose(s2, sig, rtol=1e-8)
+        np.testing.assert_allclose(c2, cs, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(m2, ms, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(lw2, lw, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
