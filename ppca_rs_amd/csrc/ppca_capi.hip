@@ -548,7 +548,7 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
     a.qtab = reinterpret_cast<signed char *>(a.qscale + 64);
 #ifdef PPCA_PHASE_TIMING
     BufRef dbg;
-    if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 12, &dbg)) return rc;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 16, &dbg)) return rc;
     a.dbg = static_cast<double *>(dbg->p);
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -565,15 +565,17 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
     HIP_TRY(launch_reduce_partials(a.part, grid, L.len, stats_dev, ctx->stream));
 #ifdef PPCA_PHASE_TIMING
     {
-        std::vector<double> h((size_t)grid * 12);
+        std::vector<double> h((size_t)grid * 16);
         HIP_TRY(hipMemcpyAsync(h.data(), a.dbg, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        double t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int g = 0; g < grid; ++g)
-            for (int i = 0; i < 12; ++i) t[i] += h[(size_t)g * 12 + i] / grid;
+            for (int i = 0; i < 16; ++i) t[i] += h[(size_t)g * 16 + i] / grid;
         const double tiles = (double)((ds->n + FUSED_TILE - 1) / FUSED_TILE) / grid;
+        fprintf(stderr, "[ppca P2 cycles/tile] mask bytes %.0f  digit pairs {7,6},{5,4} %.0f  b loop %.0f  pairs {3,2},{1,0} + stores + barrier %.0f\n",
+                t[12] / tiles, t[13] / tiles, t[14] / tiles, t[1] / tiles);
         fprintf(stderr, "[ppca phase cycles/tile] P1 %.0f  P2 %.0f  P3 %.0f (wave 0: factor %.0f, solve %.0f, columns %.0f, scalars %.0f, barrier %.0f)  P4 %.0f (cross+barrier %.0f, mask+staging %.0f, barrier %.0f)  (tiles/WG %.1f)\n",
-                (t[0] + t[5]) / tiles, t[1] / tiles, (t[2] + t[8] + t[9] + t[10] + t[11]) / tiles, t[8] / tiles, t[9] / tiles,
+                (t[0] + t[5]) / tiles, (t[1] + t[12] + t[13] + t[14]) / tiles, (t[2] + t[8] + t[9] + t[10] + t[11]) / tiles, t[8] / tiles, t[9] / tiles,
                 t[10] / tiles, t[11] / tiles, t[2] / tiles, (t[3] + t[4] + t[6] + t[7]) / tiles,
                 (t[4] + t[6]) / tiles, t[7] / tiles, t[3] / tiles, tiles);
     }

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         if (PREFETCH_A) load_pair(qbA, 6);
     }
 #ifdef PPCA_PHASE_TIMING
-    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
 #define PPCA_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
 #else
@@ -559,12 +559,14 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                             for (int u = 0; u < 4; ++u)
                                 af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
                         }
+                    PPCA_STAMP(12)
                     group(qbA, true);   // digits {7,6}: requested during the previous P4
                     load_pair(qbA, 2);
                     group(qbB, false);  // digits {5,4}
                     load_pair(qbB, 0);
                 }
             }
+            PPCA_STAMP(13)
             if constexpr (GI8) {
                 // b = X~ C alone: operands of the next four k-steps are requested before the current four
                 // MFMAs issue (hipcc otherwise reads each pair right before its MFMAs and waits on LDS)
@@ -601,6 +603,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 }
                 acc[NTP] = mfma(ax, cpc[4 * s * CS], acc[NTP]);
             }
+            PPCA_STAMP(14)
             if constexpr (GI8) {
                 group(qbA, false);  // digits {3,2}
                 group(qbB, false);  // digits {1,0}
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     }
 #ifdef PPCA_PHASE_TIMING
     if (p.dbg && tid == 0)
-        for (int i = 0; i < 12; ++i) p.dbg[(int64_t)blockIdx.x * 12 + i] = (double)tph[i];
+        for (int i = 0; i < 16; ++i) p.dbg[(int64_t)blockIdx.x * 16 + i] = (double)tph[i];
 #endif
 
     // ------------------------------------------------------------ epilogue
