@@ -104,9 +104,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int t = 0; t < 4; ++t) acc[t] = d4g_t{0, 0, 0, 0};
     const int64_t kbeg = g.part ? (int64_t)blockIdx.z * g.kslice : 0;
     const int64_t kend = g.part ? ((kbeg + g.kslice < g.K) ? kbeg + g.kslice : g.K) : g.K;
-    for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
-        // A tile: 64 (M) x 16 (K)
-        if (AMODE < 2) {
+    // The operands of K-chunk c+1 are fetched from global memory into registers before the MFMAs of chunk c and go
+    // to LDS after them: the global latency hides behind the 1024 MFMA cycles of a chunk instead of sitting between
+    // two barriers.
+    double ra[4], rb[4];
+    auto fetch = [&](int64_t k0) {
+        if (AMODE < 2) {  // A tile: 64 (M) x 16 (K); thread -> row tid / 4, four consecutive K
             const int i = tid >> 2, kk = (tid & 3) * 4;
             const int64_t row = m0 + i;
 #pragma unroll
@@ -114,38 +117,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 const int64_t col = k0 + kk + u;
                 double v = 0.0;
                 if (row < g.M && col < kend) {
-                    double x = g.X[row * g.ldx + col];
-                    bool fin = __builtin_isfinite(x);
+                    const double x = g.X[row * g.ldx + col];
+                    const bool fin = __builtin_isfinite(x);
                     v = (AMODE == 0) ? (fin ? 1.0 : 0.0) : (fin ? x - g.mean[col] : 0.0);
                 }
-                As[i][kk + u] = v;
+                ra[u] = v;
             }
-        } else {
-            const int i = tid >> 4, jj = (tid & 15) * 4;  // sample i of the K-chunk, 4 dims
+        } else {  // transposed: thread -> sample tid / 16 of the K-chunk, four consecutive dims
+            const int i = tid >> 4, jj = (tid & 15) * 4;
             const int64_t srow = k0 + i;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t dim = m0 + jj + u;
                 double v = 0.0;
                 if (srow < kend && dim < g.M) {
-                    double x = g.X[srow * g.ldx + dim];
-                    bool fin = __builtin_isfinite(x);
+                    const double x = g.X[srow * g.ldx + dim];
+                    const bool fin = __builtin_isfinite(x);
                     v = (AMODE == 2) ? (fin ? 1.0 : 0.0) : (fin ? x - g.mean[dim] : 0.0);
                 }
-                As[jj + u][i] = v;
+                ra[u] = v;
             }
         }
-        // B tile: 16 (K) x 64 (N)
-        {
+        {  // B tile: 16 (K) x 64 (N)
             const int kk = tid >> 4, cc = (tid & 15) * 4;
             const int64_t kr = k0 + kk;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t col = n0 + cc + u;
-                Bs[kk][cc + u] = (kr < kend && col < g.N) ? g.B[kr * g.ldb + col] : 0.0;
+                rb[u] = (kr < kend && col < g.N) ? g.B[kr * g.ldb + col] : 0.0;
             }
         }
+    };
+    auto stash = [&]() {
+        if (AMODE < 2) {
+            const int i = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) As[i][kk + u] = ra[u];
+        } else {
+            const int i = tid >> 4, jj = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) As[jj + u][i] = ra[u];
+        }
+        const int kk = tid >> 4, cc = (tid & 15) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Bs[kk][cc + u] = rb[u];
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
+        stash();
         __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const double a = As[16 * wave + l15][4 * s + l4];
@@ -649,7 +670,10 @@ template <int AMODE>
 static hipError_t launch_gemm(GemmArgs g, hipStream_t s, int n_cu = 256, double *part_ws = nullptr,
                               int64_t part_cap = 0) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    const int64_t tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64);
+    // (a 128 x 128 tile variant -- 2 x 2 waves of 64 x 64 -- measured slower: 11.3 vs 8.7 ms for the Gram product,
+    //  and with K = samples it leaves too few tiles for the chip)
+    constexpr int T = 64;
+    const int64_t tiles = ((g.N + T - 1) / T) * ((g.M + T - 1) / T);
     int64_t ksplit = 1;
     if (part_ws && tiles < 4 * (int64_t)n_cu) {
         ksplit = (8 * (int64_t)n_cu + tiles - 1) / tiles;
@@ -659,14 +683,14 @@ static hipError_t launch_gemm(GemmArgs g, hipStream_t s, int n_cu = 256, double 
     }
     if (ksplit <= 1) {
         g.part = nullptr;
-        dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64));
+        dim3 grid((unsigned)((g.N + T - 1) / T), (unsigned)((g.M + T - 1) / T));
         hipLaunchKernelGGL((gemm_kernel<AMODE>), grid, dim3(256), 0, s, g);
         return hipGetLastError();
     }
     g.part = part_ws;
     g.kslice = ((g.K + ksplit - 1) / ksplit + 15) / 16 * 16;
     const int nsl = (int)((g.K + g.kslice - 1) / g.kslice);
-    dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)nsl);
+    dim3 grid((unsigned)((g.N + T - 1) / T), (unsigned)((g.M + T - 1) / T), (unsigned)nsl);
     hipLaunchKernelGGL((gemm_kernel<AMODE>), grid, dim3(256), 0, s, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
