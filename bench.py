@@ -196,6 +196,8 @@ def main() -> None:
             "hbm_achieved_gbs": gbs,
             "hbm_peak_gbs": HBM_PEAK_GBS,
             "hbm_frac": gbs / HBM_PEAK_GBS,
+            "note": "bound = the larger of (algorithmic bytes / HBM peak) and (algorithmic fp64 flops / dense fp64 MFMA peak) "
+                    "per sample (SURVEY.md 8d): 0.261 ns vs 0.687 ns at d=256, k=10, so the fp64 pipe; hbm_* = the other one",
         }
         out = {
             "metric": "EM iters/sec (and samples/sec/iter) at N=10M d=256 k=10, 30% masked",
