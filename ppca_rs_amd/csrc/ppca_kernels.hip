@@ -272,10 +272,12 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             muo[c4] = (j < d) ? mMean[j] : 0.0;
         }
     }
+    // Staging lane map: a row arrives as two 16-byte loads per lane, lane l holding dims 128 h + 2 l + e
+    // (element q = 2 h + e): half as many memory and LDS-store instructions as 8-byte loads of dims 64 q + l.
     double mu[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        int j = 64 * q + lane;
+        int j = 128 * (q >> 1) + 2 * lane + (q & 1);
         mu[q] = (j < d) ? mMean[j] : 0.0;
     }
     // (a, b) of packed column c = 16 t + (lane & 15); pad columns point at the zero column K
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // tile's loads stay in flight); out-of-range rows / dims are masked when consumed in P1.
     bool dim_ok[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dim_ok[q] = 64 * q + lane < d;
+    for (int q = 0; q < 4; ++q) dim_ok[q] = 128 * (q >> 1) + 2 * lane + (q & 1) < d;
     unsigned long long dimmask[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) dimmask[q] = __builtin_amdgcn_ballot_w64(dim_ok[q]);
@@ -345,10 +347,11 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<double *>(Xwg + (int64_t)rc * p.ldx), 0, d * (int)sizeof(double), 0x00020000);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // validity is applied when consumed (P1)
-            typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-            const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, lane_entry * 8, 512 * q, 0);
-            xr[r][q] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+        for (int h = 0; h < 2; ++h) {  // validity is applied when consumed (P1)
+            typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, 0);
+            xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+            xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
         }
     };
     auto load_tile = [&](int64_t tile) {
@@ -400,21 +403,22 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // ONE compact store per array.
     int st_wlo = 0, st_whi = 0, st_m = 0, st_xlo = 0, st_xhi = 0;
     auto stage_begin = [&]() { st_wlo = st_whi = st_m = st_xlo = st_xhi = 0; };
-    // One row = 16 small pieces (each well under the 64 cycles of one fp64 MFMA) so that P4 can drop one
-    // piece behind each of its MFMAs: 2q = classify + centre quarter q, 2q+1 = file its ballot / x~ / sums,
-    // 8 = popcount, 9..14 = the six DPP steps of the row sum, 15 = row sum into its lane.
+    // One row = 14 small pieces (each well under the 64 cycles of one fp64 MFMA) so that P4 can drop one piece
+    // behind each of its MFMAs: per half h of the row, two "classify + centre" pieces (elements 2h, 2h+1) and one
+    // "file" piece (mask words, x~ pair, sums); 6 = popcount; 7..12 = the six DPP steps of the row sum, 13 = row sum
+    // into its lane.
     // (the EM pass needs only the weighted SUM of the |x~_i|^2 -- sigma^2 and the total llk are linear in it --
-    //  so it keeps one running per-lane sum, reduced once per kernel, and skips pieces 9..15)
-    constexpr int STAGE_PIECES = EM ? 9 : 16;
+    //  so it keeps one running per-lane sum, reduced once per kernel, and skips pieces 7..13)
+    constexpr int STAGE_PIECES = EM ? 7 : 14;
     double xx_run = 0.0;
-    double pc_xt = 0.0, pc_xx = 0.0;
-    unsigned long long pc_bal = 0ull;
+    double pc_xt0 = 0.0, pc_xt1 = 0.0, pc_xx = 0.0;
+    unsigned long long pc_b0 = 0ull, pc_b1 = 0ull;
     int pc_m = 0;
     auto stage_piece = [&](int64_t t, int lane, auto r_tag, auto p_tag) {
         constexpr int r = decltype(r_tag)::value, P = decltype(p_tag)::value;
         const int ri = wave * RPW + r;
-        if constexpr (P < 8 && (P & 1) == 0) {
-            constexpr int q = P / 2;
+        if constexpr (P == 0 || P == 1 || P == 3 || P == 4) {  // classify + centre element q = 2 h + e
+            constexpr int q = (P < 2) ? P : P - 1, e = q & 1;
             if constexpr (q == 0) {
                 pc_xx = 0.0;
                 pc_m = 0;
@@ -425,35 +429,56 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             // the finite test's wave mask IS the ballot; validity is ANDed in on the scalar unit
             // (|v| < inf as llvm.amdgcn.fcmp, predicate 4 = OLT: one v_cmp_lt_f64 straight into an SGPR pair;
             //  ballot(isfinite) goes through v_cmp_class + v_cndmask + v_cmp_ne)
-            pc_bal = __builtin_amdgcn_fcmp(__builtin_fabs(v), __builtin_inf(), 4) & (row_ok ? dimmask[q] : 0ull);
-            pc_xt = keep_if(v - mu[q], pc_bal);  // select, never multiply (utils.rs:118-127)
-        } else if constexpr (P < 8) {
-            constexpr int q = P / 2;
-            st_wlo = writelane_s<4 * r + q>(st_wlo, (int)(unsigned)pc_bal);
-            st_whi = writelane_s<4 * r + q>(st_whi, (int)(unsigned)(pc_bal >> 32));
-            Xs[ri * XS + 64 * q + lane] = pc_xt;
-            pc_xx += pc_xt * pc_xt;
-            pc_m += __popcll(pc_bal);
-        } else if constexpr (P == 8) {
+            const unsigned long long bal = __builtin_amdgcn_fcmp(__builtin_fabs(v), __builtin_inf(), 4) & (row_ok ? dimmask[q] : 0ull);
+            const double xt = keep_if(v - mu[q], bal);  // select, never multiply (utils.rs:118-127)
+            if constexpr (e == 0) {
+                pc_b0 = bal;
+                pc_xt0 = xt;
+            } else {
+                pc_b1 = bal;
+                pc_xt1 = xt;
+            }
+        } else if constexpr (P == 2 || P == 5) {  // file half h: mask words, x~ pair, sums
+            constexpr int h = (P == 2) ? 0 : 1;
+            // lane l tested dims 128 h + 2 l (pc_b0) and + 1 (pc_b1): the two 64-dim mask words are the bit
+            // interleaves of the ballots' low and high halves (s_bitreplicate doubles every bit; scalar unit)
+            auto weave = [&](unsigned ev, unsigned od) {
+                unsigned long long re, ro;
+                asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(re) : "s"(ev));
+                asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(ro) : "s"(od));
+                return (re & 0x5555555555555555ull) | (ro & 0xAAAAAAAAAAAAAAAAull);
+            };
+            const unsigned long long w0 = weave((unsigned)pc_b0, (unsigned)pc_b1);
+            const unsigned long long w1 = weave((unsigned)(pc_b0 >> 32), (unsigned)(pc_b1 >> 32));
+            st_wlo = writelane_s<4 * r + 2 * h>(st_wlo, (int)(unsigned)w0);
+            st_whi = writelane_s<4 * r + 2 * h>(st_whi, (int)(unsigned)(w0 >> 32));
+            st_wlo = writelane_s<4 * r + 2 * h + 1>(st_wlo, (int)(unsigned)w1);
+            st_whi = writelane_s<4 * r + 2 * h + 1>(st_whi, (int)(unsigned)(w1 >> 32));
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 * h + 2 * lane) = d2_t{pc_xt0, pc_xt1};  // 16-byte aligned
+            pc_xx += pc_xt0 * pc_xt0;
+            pc_xx += pc_xt1 * pc_xt1;
+            pc_m += __popcll(pc_b0) + __popcll(pc_b1);
+        } else if constexpr (P == 6) {
             st_m = writelane<r>(st_m, pc_m);
             if constexpr (EM) {
                 const int64_t row = t * B + ri;
                 const double wr = p.w ? p.w[row < n ? row : n - 1] : 1.0;  // wave-uniform (scalar load)
                 xx_run += wr * pc_xx;
             }
-        } else if constexpr (P == 9) {
+        } else if constexpr (P == 7) {
             pc_xx += dpp_f64<0xB1, 0xF>(pc_xx);   // quad_perm [1,0,3,2]
-        } else if constexpr (P == 10) {
+        } else if constexpr (P == 8) {
             pc_xx += dpp_f64<0x4E, 0xF>(pc_xx);   // quad_perm [2,3,0,1]
-        } else if constexpr (P == 11) {
+        } else if constexpr (P == 9) {
             pc_xx += dpp_f64<0x141, 0xF>(pc_xx);  // row_half_mirror
-        } else if constexpr (P == 12) {
+        } else if constexpr (P == 10) {
             pc_xx += dpp_f64<0x140, 0xF>(pc_xx);  // row_mirror
-        } else if constexpr (P == 13) {
+        } else if constexpr (P == 11) {
             pc_xx += dpp_f64<0x142, 0xA>(pc_xx);  // row_bcast15
-        } else if constexpr (P == 14) {
+        } else if constexpr (P == 12) {
             pc_xx += dpp_f64<0x143, 0xC>(pc_xx);  // row_bcast31: lane 63 = total
-        } else if constexpr (P == 15) {
+        } else if constexpr (P == 13) {
             const long long tb = __double_as_longlong(pc_xx);
             st_xlo = writelane<r>(st_xlo, __builtin_amdgcn_readlane((int)tb, 63));
             st_xhi = writelane<r>(st_xhi, __builtin_amdgcn_readlane((int)(tb >> 32), 63));
@@ -782,7 +807,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 for (int r = 0; r < RT; ++r) axb[0][r] = Xs[l4 * XS + DW * wave + 16 * r + l15];
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    if (s < RPW) load_row(tile + 1, s);  // unconditional (clamped rows)
+                    if (s < RPW) load_row(tile + 1, s);  // unconditional (clamped rows); two rows per step measured slower
                     if (s + 1 < 8) {
                         const int smp = 4 * (s + 1) + l4;
                         bzb[(s + 1) & 1] = Ws[smp * WS + 16 * NTP + l15];
