@@ -1323,9 +1323,10 @@ static bool gram_i8() {
     return v == 1;
 }
 
-// Waves per workgroup of the EM pass: 4 (one per SIMD, 512 registers each).  PPCA_FUSED_WAVES=8
-// selects the two-waves-per-SIMD variant, measured slower in round 1 (25.5 vs 38.4 EM it/s at
-// N = 10M: the per-sample solve spills at 256 registers and the MFMA phases do not speed up).
+// Waves per workgroup of the EM pass: 4 (one per SIMD, 512 registers each).  PPCA_FUSED_WAVES=8 selects the
+// two-waves-per-SIMD variant (fp64-MFMA Gram), kept as a measured alternative: 182 vs 357 EM it/s at N = 2 M at the
+// end of round 1 -- the per-sample solve spills at 256 registers and both waves of a SIMD sit in the same phase, so
+// there is no MFMA time for the other's vector work to hide in.  PPCA_GRAM_FP64=1 (fp64-MFMA Gram, 4 waves): 240.
 static int em_waves() {
     static int nw = 0;
     if (nw == 0) {
