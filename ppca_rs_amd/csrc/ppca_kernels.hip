@@ -572,14 +572,23 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             i4_t qbB[2][4];
             if constexpr (GI8) {
                 {
+                    // (the mask words are requested from LDS first, so that their latency runs under the issue of
+                    //  the table loads)
+                    unsigned long long mwd[2][4];
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) mwd[rt2][kc] = Msc[(16 * rt2 + l15) * 4 + kc];
+                    __builtin_amdgcn_sched_barrier(0);
                     if (!PREFETCH_A) load_pair(qbA, 6);
                     load_pair(qbB, 4);
                     if (gram_wave) qs = p.qscale[16 * wave + l15];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rt2 = 0; rt2 < 2; ++rt2)
 #pragma unroll
                         for (int kc = 0; kc < 4; ++kc) {
-                            const unsigned bits = (unsigned)(Msc[(16 * rt2 + l15) * 4 + kc] >> (16 * l4)) & 0xFFFFu;
+                            const unsigned bits = (unsigned)(mwd[rt2][kc] >> (16 * l4)) & 0xFFFFu;
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
                                 af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
@@ -829,18 +838,18 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 // across P4 as well spills 73 registers
                 if (PREFETCH_A) load_pair(qbA, 6);
             }
-            // One staging piece follows each MFMA.  Measured (tools/ubench_shadow.hip): v_mfma_f64 holds the
-            // SIMD's VALU port for its 64 cycles -- no VALU instruction of this wave overlaps it, only LDS,
-            // SALU and memory instructions do -- so this interleave hides the staging's LDS writes and the
-            // row-load latency, not its ALU work.  The B operands of step s+1 are read from LDS during step s.
             unsigned long long mwc = Msc[l4 * 4 + (DW * wave) / 64];
             double bwc[NTMB], bsc = 0.0;
 #pragma unroll
             for (int t = 0; t < NTMB; ++t) bwc[t] = Ws[l4 * WS + 16 * t + l15];
+            if constexpr (SPLIT) bsc = Ws[l4 * WS + 16 * NTP + PADS + (lane & 3)];
+            // One staging piece follows each MFMA.  Measured (tools/ubench_shadow.hip): v_mfma_f64 holds the
+            // SIMD's VALU port for its 64 cycles -- no VALU instruction of this wave overlaps it, only LDS,
+            // SALU and memory instructions do -- so this interleave hides the staging's LDS writes and the
+            // row-load latency, not its ALU work.  The B operands of step s+1 are read from LDS during step s.
             // B operand of the 4x4x4 blocks: lane = 16 k + 4 block + j -> W[sample 4 s + k][column j of the group];
             // its A operand (lane = 16 k + 4 block + i -> dim 4 block + i, sample k) is the SAME register as the
             // 16x16x4 tiles' (row = lane % 16, k = lane / 16): no extra mask expansion.
-            if constexpr (SPLIT) bsc = Ws[l4 * WS + 16 * NTP + PADS + (lane & 3)];
             static_for<8>([&](auto s_tag) {
                 constexpr int s = decltype(s_tag)::value;
                 unsigned long long mwn = 0ull;
