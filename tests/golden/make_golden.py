@@ -48,7 +48,34 @@ def case(name, n, d, k, mask_prob, seed, iters=3, weights=False, prior=None):
     print(name, "llk", out["llk"], "sigma", sigs)
 
 
+def mix_case(name, n, d, k, nm, seed, iters=3):
+    """A mixture fixture (in its own directory entry `mix_*.npz`): inputs, three iterations of the oracle's mixture
+    EM with weights, and the mixture's inference outputs (mix.rs:137-189, :281-337, :352-505)."""
+    rng = np.random.default_rng(seed)
+    x = np.concatenate([o.synth(n // nm, d, k, 0.3, seed + 10 * c, mean_scale=2.5)[0] for c in range(nm)])
+    rng.shuffle(x)
+    x[2, :] = np.nan
+    w = rng.uniform(0.5, 2.0, x.shape[0])
+    sig, cs, ms = rng.uniform(0.6, 1.2, nm), rng.standard_normal((nm, d, k)), rng.standard_normal((nm, d))
+    lw = np.log(rng.dirichlet(np.ones(nm)))
+    out = dict(x=x, w=w, sig0=sig, cs0=cs, ms0=ms, lw0=lw)
+    out["llks"] = o.mix_llks(x, sig, cs, ms, lw)
+    inf = o.mix_inferred(x, sig, cs, ms, lw)
+    for key in ("log_posterior", "state", "covariance", "smooth", "extrapolate", "smooth_covariance_diagonal",
+                "extrapolate_covariance_diagonal"):
+        out["inf_" + key] = inf[key]
+    sigs, css, mss, lws, llks = [], [], [], [], []
+    for _ in range(iters):
+        llks.append(float((o.mix_llks(x, sig, cs, ms, lw) * w).sum()))
+        sig, cs, ms, lw = o.mix_iterate(x, sig, cs, ms, lw, w)
+        sigs.append(sig); css.append(cs); mss.append(ms); lws.append(lw)
+    out["it_sigma"], out["it_c"], out["it_mean"], out["it_lw"], out["it_llk"] = map(np.array, (sigs, css, mss, lws, llks))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "llk", llks)
+
+
 if __name__ == "__main__":
+    mix_case("mix_d16_k3_m3", 360, 16, 3, 3, 71)
     case("toy_d3_k2", 100, 3, 2, 0.2, 11, iters=5)
     case("small_d12_k3", 300, 12, 3, 0.3, 21, iters=3)
     case("weighted_d20_k4", 200, 20, 4, 0.3, 31, iters=3, weights=True)

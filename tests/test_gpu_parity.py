@@ -10,7 +10,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+              if not os.path.basename(p).startswith("mix_"))
+GOLD_MIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mix_*.npz")))
 RTOL = 1e-5  # north_star tolerance
 
 
@@ -68,6 +70,31 @@ def test_golden(P, path):
         assert _rel(m.transform, g["it_c"][it]) < RTOL * 1e-1
         assert _rel(m.mean, g["it_mean"][it]) < RTOL * 1e-1
     assert _rel(m.to_canonical().transform, g["canonical"]) < RTOL
+
+
+@pytest.mark.parametrize("path", GOLD_MIX, ids=[os.path.basename(p) for p in GOLD_MIX])
+def test_golden_mixture(P, path):
+    """The HIP path against the committed mixture fixture (no oracle at run time): llks, inference outputs, three
+    weighted mixture EM iterations."""
+    g = np.load(path)
+    x, w, sig, cs, ms, lw = g["x"], g["w"], g["sig0"], g["cs0"], g["ms0"], g["lw0"]
+    ds = P.Dataset(x, w)
+    mix = P.PPCAMix([P.PPCAModel(sig[c], cs[c], ms[c]) for c in range(len(sig))], lw)
+    assert _rel(mix.llks(ds), g["llks"]) < 1e-9
+    inf = mix.infer(ds)
+    assert _rel(inf.log_posteriors(), g["inf_log_posterior"]) < 1e-8
+    assert _rel(inf.states(), g["inf_state"]) < 1e-8 and _rel(np.array(inf.covariances()), g["inf_covariance"]) < 1e-8
+    assert _rel(mix.smooth(ds).numpy(), g["inf_smooth"]) < 1e-8
+    assert _rel(mix.extrapolate(ds).numpy(), g["inf_extrapolate"]) < 1e-8
+    assert _rel(mix._mix_recon(ds, 2).numpy(), g["inf_smooth_covariance_diagonal"]) < 1e-8
+    assert _rel(mix._mix_recon(ds, 3).numpy(), g["inf_extrapolate_covariance_diagonal"]) < 1e-8
+    for it in range(len(g["it_llk"])):
+        mix, llk = mix.iterate_with_llk(ds)
+        assert abs(llk - g["it_llk"][it]) < 1e-8 * abs(g["it_llk"][it])
+        for c, mdl in enumerate(mix.models):
+            assert abs(mdl.isotropic_noise - g["it_sigma"][it][c]) < RTOL * 1e-1 * g["it_sigma"][it][c]
+            assert _rel(mdl.transform, g["it_c"][it][c]) < RTOL and _rel(mdl.mean, g["it_mean"][it][c]) < RTOL
+        assert _rel(mix.log_weights, g["it_lw"][it]) < RTOL
 
 
 def test_stats_raw_against_oracle(P, oracle):

@@ -6,7 +6,9 @@ import os
 import numpy as np
 import pytest
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+              if not os.path.basename(p).startswith("mix_"))
+GOLD_MIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mix_*.npz")))
 C_TOY = np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]])  # ppca_model.rs:647-656
 
 
@@ -158,3 +160,21 @@ def test_fused_cpu_stats_match_literal_stats(oracle):
         want = o.stats(x, 0.7, c0, mu0, weights)
         got = o.fused_stats(x, 0.7, c0, mu0, weights)
         assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("path", GOLD_MIX, ids=[os.path.basename(p) for p in GOLD_MIX])
+def test_golden_mixture_vectors(oracle, path):
+    """The committed mixture fixture is what the oracle computes today (tests/golden/make_golden.py::mix_case)."""
+    g = np.load(path)
+    x, w, sig, cs, ms, lw = g["x"], g["w"], g["sig0"], g["cs0"], g["ms0"], g["lw0"]
+    np.testing.assert_allclose(oracle.mix_llks(x, sig, cs, ms, lw), g["llks"], rtol=1e-12)
+    inf = oracle.mix_inferred(x, sig, cs, ms, lw)
+    for key in ("log_posterior", "state", "covariance", "smooth", "extrapolate", "smooth_covariance_diagonal",
+                "extrapolate_covariance_diagonal"):
+        np.testing.assert_allclose(inf[key], g["inf_" + key], rtol=1e-10, atol=1e-12)
+    for it in range(len(g["it_llk"])):
+        assert abs(float((oracle.mix_llks(x, sig, cs, ms, lw) * w).sum()) - g["it_llk"][it]) < 1e-10 * abs(g["it_llk"][it])
+        sig, cs, ms, lw = oracle.mix_iterate(x, sig, cs, ms, lw, w)
+        np.testing.assert_allclose(sig, g["it_sigma"][it], rtol=1e-10)
+        np.testing.assert_allclose(cs, g["it_c"][it], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(lw, g["it_lw"][it], rtol=1e-10, atol=1e-13)
