@@ -90,15 +90,30 @@ def main() -> None:
     ap.add_argument("--cpu-rows", type=int, default=100_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU tests)")
+    ap.add_argument("--collective", default="auto", choices=["auto", "capi", "torch"],
+                    help="who runs the all-reduce of the statistics: the library's own RCCL communicator behind the "
+                         "C-ABI (capi), torch.distributed (torch), or capi with torch as the fallback if the "
+                         "communicator cannot be created (auto)")
     ap.add_argument("--dump-model", default=None, help="rank 0 writes the final model to this .npz (tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: start N fresh ranks (one per GPU) as CHILD processes and relay rank 0's
+        # JSON line.  Nothing in this process has touched torch or the GPU yet, and it never will.
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     import torch
@@ -136,7 +151,28 @@ def main() -> None:
     c0 = np.random.default_rng(2011).standard_normal(d * k).reshape((k, d)).T.copy()
     start = P.PPCAModel(1.0, c0, np.zeros(d))  # as PPCAModel::init (ppca_model.rs:51-70)
 
-    em = ShardedEM(shard, start)
+    # The one collective of the path.  Default: the library's own RCCL communicator (ppca_comm, behind the C-ABI);
+    # torch.distributed carries only the rendezvous (unique id), the barrier and the max-over-ranks of the clock.
+    comm, collective = None, "none (single rank)"
+    if world > 1:
+        collective = f"torch.distributed all_reduce ({args.backend})"
+        if args.collective in ("auto", "capi") and args.backend == "nccl":
+            from ppca_rs_amd.distributed import Communicator
+
+            try:
+                comm = Communicator.from_torch(ctx)
+                collective = "ppca_em_step_sharded: " + Communicator.backend()
+            except Exception as e:  # noqa: BLE001
+                if args.collective == "capi":
+                    raise
+                print(f"[bench rank {rank}] C-ABI communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            # all ranks must agree on the path
+            flag = torch.tensor([1 if comm is not None else 0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and comm is not None:
+                comm.close()
+                comm, collective = None, f"torch.distributed all_reduce ({args.backend})"
+    em = ShardedEM(shard, start, comm=comm)
 
     def sync():
         torch.cuda.synchronize()
@@ -214,6 +250,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"PPCA EM, N={n} samples x d={d}, state_size={k}, {int(100 * args.mask)}% iid masked, "
                                    f"{world} contiguous row shard(s), one all-reduce of {_lib.lib().ppca_stats_len(d, k)} f64 per step",
+                       "collective": collective,
                        "n_samples": n, "d": d, "state_size": k, "mask_prob": args.mask, "parallelism": f"dp{world}"},
             "samples_per_sec": n * iters_per_s,
             "llk_per_sample_last_input_model": llk_last / n,
@@ -229,6 +266,8 @@ def main() -> None:
         print(json.dumps(out), flush=True)
 
     em.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPCA_ABI_VERSION 1
+#define PPCA_ABI_VERSION 2
 
 typedef enum ppca_status {
     PPCA_OK = 0,
@@ -177,6 +177,10 @@ int ppca_em_finalize_host(int32_t d, int32_t k, double sigma, const double *tran
  * Reading llk_in synchronises; with llk_in == NULL the call is asynchronous. */
 int ppca_em_step(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model_in, const ppca_prior *prior,
                  ppca_model *out, double *llk_in);
+/* The log-likelihood by-product of the most recent ppca_em_step / ppca_em_step_sharded / ppca_em_step_group on
+ * this context (the llk of THAT step's input model, over all shards), for callers that ran the step
+ * asynchronously.  Synchronises. */
+int ppca_em_last_llk(ppca_ctx *ctx, double *llk);
 /* Debug/parity: the packed statistics copied to host. */
 int ppca_stats_raw(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_host);
 
@@ -195,6 +199,39 @@ int ppca_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, i
  * extrapolated_covariance_diagonal :542-577 (mode 1; observed dims -> 0). */
 int ppca_covariance_diagonal(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, int32_t mode,
                              ppca_dataset **out);
+
+/* ------------------------------------------- sample-sharded EM across GPUs */
+/* The dataset shards by contiguous row blocks (the rule of Dataset.chunks, src/python_bindings.rs:110-118); every
+ * statistic above is a weighted sum over samples, so ONE all-reduce(sum) of the packed buffer per iteration
+ * replaces the reference's in-process rayon reductions (ppca_model.rs:290-293, :350-358), and every rank finalises
+ * the same model.  The collective is RCCL (resolved at run time with dlopen) on the context stream.
+ *
+ * One process (or thread) per GPU:  rank 0 calls ppca_comm_unique_id, the host ships the 128 bytes to the other
+ * ranks by its own means (MPI, a file, torch.distributed's store), every rank calls ppca_comm_create -- a
+ * collective call.  One thread driving several GPUs: ppca_comm_create_all + ppca_em_step_group. */
+typedef struct ppca_comm ppca_comm;
+#define PPCA_UNIQUE_ID_BYTES 128
+int ppca_comm_unique_id(void *id_out /* PPCA_UNIQUE_ID_BYTES */);
+int ppca_comm_create(ppca_ctx *ctx, int32_t n_ranks, int32_t rank, const void *unique_id, ppca_comm **out);
+/* n contexts on n distinct devices of this process -> n communicators (out[n]) of one clique. */
+int ppca_comm_create_all(ppca_ctx *const *ctxs, int32_t n, ppca_comm **out);
+int ppca_comm_destroy(ppca_comm *comm);
+int32_t ppca_comm_n_ranks(const ppca_comm *comm);
+int32_t ppca_comm_rank(const ppca_comm *comm);
+/* "rccl <version> via <library>" or "unavailable: <why>". */
+const char *ppca_comm_backend(void);
+/* In-place all-reduce of n doubles of device memory over the ranks, on the context stream (asynchronous).
+ * op 0 = sum, 1 = max (the mixture's per-component maxima, mix.rs:312-317). */
+int ppca_comm_allreduce(ppca_comm *comm, double *buf_dev, int64_t n, int32_t op);
+/* PPCAModel::iterate_with_prior (ppca_model.rs:277-393) over ALL shards: this rank's ppca_em_accumulate, the
+ * all-reduce, ppca_em_finalize -- enqueued back to back on the context stream, no host synchronisation unless
+ * llk_in (log-likelihood of model_in over all shards) is requested.  A rank whose shard is empty still calls. */
+int ppca_em_step_sharded(ppca_comm *comm, ppca_dataset *shard, const ppca_model *model_in, const ppca_prior *prior,
+                         ppca_model *out, double *llk_in);
+/* The same from ONE host thread for the n communicators of ppca_comm_create_all (shards[i], models_in[i],
+ * models_out[i] live on comms[i]'s device; the all-reduces are issued as one RCCL group). */
+int ppca_em_step_group(ppca_comm *const *comms, int32_t n, ppca_dataset *const *shards, ppca_model *const *models_in,
+                       const ppca_prior *prior, ppca_model *const *models_out, double *llk_in);
 
 /* ---------------------------------------------------------------- mixture */
 /* PPCAMix::iterate_with_prior mix.rs:281-337 on one GPU: per-sample
@@ -232,6 +269,13 @@ int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *mod
                          int32_t n_models, int32_t mode, ppca_dataset **out);
 
 /* ------------------------------------------------------------------ debug */
+/* Which Gram engine the fused passes use for this model: 0 = int8-sliced MFMA with exact integer accumulation,
+ * 1 = fp64 MFMA.  Decided on the device per model by a dynamic-range guard (the int8 form keeps 54 bits below each
+ * column maximum of vech(c c^T); a model whose rows of C span many orders of magnitude, or whose sigma^2 lies
+ * below that resolution, takes the fp64 form; see ppca_kernels.hip, qprep_kernel).  Stands where the reference
+ * computes C_o^T C_o in f64 (output_covariance.rs:57-70).  Synchronises. */
+int ppca_gram_engine(ppca_ctx *ctx, const ppca_model *model, int32_t *engine);
+
 /* One v_mfma_f64_16x16x4_f64 on host-supplied A (16 x 4) and B (4 x 16), result
  * (16 x 16) written through the C/D lane map the kernels assume (unit test). */
 int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const double *b4x16, double *out16x16);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ppca_em_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), C.c_void_p]),
     "ppca_em_finalize_host": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), c_double_p, C.c_void_p, C.c_void_p]),
     "ppca_em_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), C.c_void_p, c_double_p]),
+    "ppca_em_last_llk": (C.c_int, [C.c_void_p, c_double_p]),
     "ppca_stats_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppca_llk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_double_p, C.c_void_p]),
     "ppca_llks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -104,6 +105,17 @@ SIGNATURES = {
     "ppca_vector_exp_shift_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p]),
     "ppca_vector_sum_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_double_p]),
     "ppca_mix_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, C.c_int32, c_void_pp]),
+    "ppca_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ppca_comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, c_void_pp]),
+    "ppca_comm_create_all": (C.c_int, [c_void_pp, C.c_int32, c_void_pp]),
+    "ppca_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ppca_comm_n_ranks": (C.c_int32, [C.c_void_p]),
+    "ppca_comm_rank": (C.c_int32, [C.c_void_p]),
+    "ppca_comm_backend": (C.c_char_p, []),
+    "ppca_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "ppca_em_step_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), C.c_void_p, c_double_p]),
+    "ppca_em_step_group": (C.c_int, [c_void_pp, C.c_int32, c_void_pp, c_void_pp, C.POINTER(Prior), c_void_pp, c_double_p]),
+    "ppca_gram_engine": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p]),
     "ppca_debug_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppca_debug_mfma_i8_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -10,18 +10,19 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
-#include "../../include/ppca_hip.h"
-#include "ppca_internal.hpp"
+#include "ppca_handles.hpp"
 
 using namespace ppca;
+using namespace ppca_host;
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 
-static int fail(int code, const char *fmt, ...) {
+int ppca_host::fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -31,75 +32,20 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t _e = (expr);                                                                         \
-        if (_e != hipSuccess) return fail(PPCA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
-    } while (0)
-
-// ------------------------------------------------------------------ handles
-struct DevBuf {
-    void *p = nullptr;
-    bool owned = true;
-    int device = 0;
-    ~DevBuf() {
-        if (p && owned) (void)hipFree(p);
-    }
-};
-typedef std::shared_ptr<DevBuf> BufRef;
-
-static int dev_alloc(size_t bytes, BufRef *out) {
+int ppca_host::dev_alloc(size_t bytes, BufRef *out) {
     auto b = std::make_shared<DevBuf>();
     if (bytes == 0) bytes = 8;
     HIP_TRY(hipMalloc(&b->p, bytes));
     *out = b;
     return PPCA_OK;
 }
-static BufRef dev_borrow(const void *p) {
+BufRef ppca_host::dev_borrow(const void *p) {
     auto b = std::make_shared<DevBuf>();
     b->p = const_cast<void *>(p);
     b->owned = false;
     return b;
 }
-
-struct ppca_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int n_cu = 256;
-    bool timing = false;
-    int skip_llk = 0;  // internal: set around the mixture's component EM steps (PassArgs::no_llk)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    BufRef part;  // per-workgroup partial statistics
-    size_t part_cap = 0;
-    BufRef stats;  // scratch statistics buffer (em_step, stats_raw)
-    size_t stats_cap = 0;
-    BufRef scal;  // post-pass scalars: [grid][8] partials + 8 reduced
-    size_t scal_cap = 0;
-    BufRef work;  // 2048 doubles for reductions
-    BufRef qtab;  // int8 Gram slice table + scales of the model being processed
-    size_t qtab_cap = 0;
-    BufRef gws;   // workspace of the generic split pipeline
-    size_t gws_cap = 0;
-};
-
-struct ppca_dataset {
-    ppca_ctx *ctx = nullptr;
-    BufRef xbuf, wbuf;
-    const double *X = nullptr;
-    const double *w = nullptr;  // nullptr = all ones
-    int64_t n = 0;
-    int d = 0;
-};
-
-struct ppca_model {
-    ppca_ctx *ctx = nullptr;
-    int d = 0, k = 0;
-    BufRef buf;
-    double *p() const { return static_cast<double *>(buf->p); }
-};
-
-static int ensure(BufRef &b, size_t &cap, size_t bytes) {
+int ppca_host::ensure(BufRef &b, size_t &cap, size_t bytes) {
     if (cap >= bytes && b) return PPCA_OK;
     BufRef nb;
     int rc = dev_alloc(bytes, &nb);
@@ -108,8 +54,7 @@ static int ensure(BufRef &b, size_t &cap, size_t bytes) {
     cap = bytes;
     return PPCA_OK;
 }
-
-static int use_device(const ppca_ctx *ctx) {
+int ppca_host::use_device(const ppca_ctx *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     return PPCA_OK;
 }
@@ -182,7 +127,7 @@ extern "C" int ppca_ctx_destroy(ppca_ctx *ctx) {
 
 extern "C" int ppca_ctx_set_stream(ppca_ctx *ctx, void *stream) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) {
         (void)hipStreamDestroy(ctx->stream);
@@ -199,20 +144,21 @@ extern "C" int ppca_ctx_set_stream(ppca_ctx *ctx, void *stream) {
 
 extern "C" int ppca_ctx_synchronize(ppca_ctx *ctx) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PPCA_OK;
 }
 
 extern "C" int ppca_ctx_enable_timing(ppca_ctx *ctx, int32_t enabled) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::recursive_mutex> ctx_lock_(ctx->mu);
     ctx->timing = enabled != 0;
     return PPCA_OK;
 }
 
 extern "C" int ppca_ctx_kernel_time(ppca_ctx *ctx, double *total_ms, int64_t *launches, int32_t reset) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     double tot = 0.0;
     for (auto &ev : ctx->events) {
@@ -236,7 +182,7 @@ extern "C" int ppca_ctx_kernel_time(ppca_ctx *ctx, double *total_ms, int64_t *la
 extern "C" int ppca_dataset_from_host(ppca_ctx *ctx, const double *x, int64_t n, int32_t d, int64_t row_stride,
                                       int64_t col_stride, const double *weights, ppca_dataset **out) {
     if (!ctx || !out || n < 0 || d < 1 || (n > 0 && !x)) return fail(PPCA_ERR_INVALID, "bad dataset arguments");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     auto ds = std::make_unique<ppca_dataset>();
     ds->ctx = ctx;
     ds->n = n;
@@ -296,7 +242,7 @@ extern "C" int ppca_dataset_generate(ppca_ctx *ctx, const ppca_synth_spec *spec,
         return fail(PPCA_ERR_INVALID, "bad synth spec");
     if (spec->mask_kind == 0 && !(spec->mask_prob >= 0.0 && spec->mask_prob <= 1.0))
         return fail(PPCA_ERR_INVALID, "invalid mask probability");  // ppca_model.rs:171
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     const int d = spec->d, k = spec->k;
     const int64_t n = spec->n_rows;
     auto ds = std::make_unique<ppca_dataset>();
@@ -328,7 +274,7 @@ extern "C" int ppca_dataset_generate(ppca_ctx *ctx, const ppca_synth_spec *spec,
 extern "C" int ppca_dataset_with_weights(ppca_dataset *ds, const double *weights_host, const double *weights_dev,
                                          ppca_dataset **out) {
     if (!ds || !out) return fail(PPCA_ERR_INVALID, "null argument");
-    if (int rc = use_device(ds->ctx)) return rc;
+    USE_CTX(ds->ctx);
     auto nd = std::make_unique<ppca_dataset>(*ds);
     if (weights_dev) {
         nd->wbuf = dev_borrow(weights_dev);
@@ -362,7 +308,7 @@ extern "C" int ppca_dataset_slice(ppca_dataset *ds, int64_t start, int64_t len, 
 extern "C" int ppca_dataset_concat(ppca_ctx *ctx, ppca_dataset *const *parts, int32_t n_parts, ppca_dataset **out) {
     if (!ctx || !out || n_parts < 0 || (n_parts > 0 && !parts)) return fail(PPCA_ERR_INVALID, "null argument");
     if (n_parts == 0) return fail(PPCA_ERR_EMPTY, "cannot concatenate an empty list");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     int64_t n = 0;
     const int d = parts[0]->d;
     for (int i = 0; i < n_parts; ++i) {
@@ -411,7 +357,7 @@ extern "C" const double *ppca_dataset_device_weights(const ppca_dataset *ds) { r
 extern "C" int ppca_dataset_to_host(ppca_dataset *ds, double *out) {
     if (!ds || (!out && ds->n > 0)) return fail(PPCA_ERR_INVALID, "null argument");
     if (ds->n == 0) return PPCA_OK;
-    if (int rc = use_device(ds->ctx)) return rc;
+    USE_CTX(ds->ctx);
     HIP_TRY(hipStreamSynchronize(ds->ctx->stream));
     HIP_TRY(hipMemcpy(out, ds->X, sizeof(double) * (size_t)ds->n * ds->d, hipMemcpyDeviceToHost));
     // masked_vector (dataset.rs:64-72): masked -> NaN; +-inf inputs are masked, so they come back NaN too
@@ -428,7 +374,7 @@ extern "C" int ppca_dataset_weights_to_host(ppca_dataset *ds, double *out) {
         for (int64_t i = 0; i < ds->n; ++i) out[i] = 1.0;
         return PPCA_OK;
     }
-    if (int rc = use_device(ds->ctx)) return rc;
+    USE_CTX(ds->ctx);
     HIP_TRY(hipStreamSynchronize(ds->ctx->stream));
     HIP_TRY(hipMemcpy(out, ds->w, sizeof(double) * (size_t)ds->n, hipMemcpyDeviceToHost));
     return PPCA_OK;
@@ -437,7 +383,7 @@ extern "C" int ppca_dataset_weights_to_host(ppca_dataset *ds, double *out) {
 extern "C" int ppca_dataset_empty_dimensions(ppca_dataset *ds, int32_t *flags) {
     if (!ds || !flags) return fail(PPCA_ERR_INVALID, "null argument");
     ppca_ctx *ctx = ds->ctx;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     BufRef pres;
     if (int rc = dev_alloc(sizeof(int) * (size_t)ds->d, &pres)) return rc;
     HIP_TRY(hipMemsetAsync(pres->p, 0, sizeof(int) * (size_t)ds->d, ctx->stream));
@@ -452,7 +398,7 @@ extern "C" int ppca_dataset_empty_dimensions(ppca_dataset *ds, int32_t *flags) {
 // ------------------------------------------------------------------ model
 extern "C" int ppca_model_alloc(ppca_ctx *ctx, int32_t d, int32_t k, ppca_model **out) {
     if (!ctx || !out || d < 1 || k < 0) return fail(PPCA_ERR_INVALID, "bad model shape");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     auto m = std::make_unique<ppca_model>();
     m->ctx = ctx;
     m->d = d;
@@ -486,7 +432,7 @@ extern "C" int ppca_model_create(ppca_ctx *ctx, int32_t d, int32_t k, double sig
 
 extern "C" int ppca_model_download(ppca_model *m, double *sigma, double *transform, double *mean) {
     if (!m) return fail(PPCA_ERR_INVALID, "null model");
-    if (int rc = use_device(m->ctx)) return rc;
+    USE_CTX(m->ctx);
     std::vector<double> h((size_t)model_len(m->d, m->k));
     HIP_TRY(hipMemcpyAsync(h.data(), m->p(), sizeof(double) * h.size(), hipMemcpyDeviceToHost, m->ctx->stream));
     HIP_TRY(hipStreamSynchronize(m->ctx->stream));
@@ -520,7 +466,7 @@ static int check_pair(const ppca_dataset *ds, const ppca_model *model) {
 extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_dev) {
     if (!ctx || !stats_dev) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     const StatsLayout L(model->d, model->k);
     if (ds->n == 0) {
         HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * (size_t)L.len, ctx->stream));
@@ -544,8 +490,7 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
     a.part = static_cast<double *>(ctx->part->p);
     a.no_llk = ctx->skip_llk;
     if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
-    a.qscale = static_cast<double *>(ctx->qtab->p);
-    a.qtab = reinterpret_cast<signed char *>(a.qscale + 64);
+    fused_qtab_layout(ctx->qtab->p, a);
 #ifdef PPCA_PHASE_TIMING
     BufRef dbg;
     if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 16, &dbg)) return rc;
@@ -694,7 +639,7 @@ extern "C" int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const
     if (out->d != model_in->d || out->k != model_in->k) return fail(PPCA_ERR_INVALID, "model shapes differ");
     if (int rc = check_path(model_in->d, model_in->k)) return rc;
     if (int rc = check_prior(prior)) return rc;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     const int d = model_in->d, k = model_in->k;
     const double tau = prior ? prior->transformation_precision : 0.0;
     const int has_ig = prior ? prior->has_isotropic_noise_prior : 0;
@@ -730,11 +675,13 @@ extern "C" int ppca_em_step(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *m
     if (!ctx || !out) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model_in)) return rc;
     if (ds->n == 0) return fail(PPCA_ERR_EMPTY, "dataset is empty");
+    USE_CTX(ctx);
     const StatsLayout L(model_in->d, model_in->k);
     if (int rc = ensure(ctx->stats, ctx->stats_cap, sizeof(double) * (size_t)L.len)) return rc;
     double *stats = static_cast<double *>(ctx->stats->p);
     if (int rc = ppca_em_accumulate(ctx, ds, model_in, stats)) return rc;
     if (int rc = ppca_em_finalize(ctx, model_in, stats, prior, out)) return rc;
+    ctx->stats_llk_at = L.scalars + SC_LLK;
     if (llk_in) {
         HIP_TRY(hipMemcpyAsync(llk_in, stats + L.scalars + SC_LLK, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -742,12 +689,24 @@ extern "C" int ppca_em_step(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *m
     return PPCA_OK;
 }
 
+extern "C" int ppca_em_last_llk(ppca_ctx *ctx, double *llk) {
+    if (!ctx || !llk) return fail(PPCA_ERR_INVALID, "null argument");
+    USE_CTX(ctx);
+    if (ctx->stats_llk_at < 0 || !ctx->stats) return fail(PPCA_ERR_INVALID, "no EM step has run on this context");
+    HIP_TRY(hipMemcpyAsync(llk, static_cast<double *>(ctx->stats->p) + ctx->stats_llk_at, sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
 extern "C" int ppca_stats_raw(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_host) {
     if (!ctx || !stats_host) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
+    USE_CTX(ctx);
     const StatsLayout L(model->d, model->k);
     if (int rc = ensure(ctx->stats, ctx->stats_cap, sizeof(double) * (size_t)L.len)) return rc;
     double *stats = static_cast<double *>(ctx->stats->p);
+    ctx->stats_llk_at = -1;
     if (int rc = ppca_em_accumulate(ctx, ds, model, stats)) return rc;
     HIP_TRY(hipMemcpyAsync(stats_host, stats, sizeof(double) * (size_t)L.len, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -758,7 +717,7 @@ extern "C" int ppca_stats_raw(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
 // Runs pass_kernel<K, false>; scalars (if wanted) end up in ctx->scal[grid*8 .. grid*8+8).
 static int run_post(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *llks_dev, double *states_dev,
                     double *covs_dev, double *recon_dev, int recon_mode, double **scal_out) {
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     if (ppca_path_kind(model->d, model->k) == 0) {
         if (int rc = ensure(ctx->scal, ctx->scal_cap, sizeof(double) * 16)) return rc;
         if (int rc = ensure(ctx->gws, ctx->gws_cap, generic_workspace_bytes(model->d, model->k, ds->n))) return rc;
@@ -788,8 +747,7 @@ static int run_post(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, do
         a.recon = recon_dev;
         a.recon_mode = recon_mode;
         if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
-        a.qscale = static_cast<double *>(ctx->qtab->p);
-        a.qtab = reinterpret_cast<signed char *>(a.qscale + 64);
+        fused_qtab_layout(ctx->qtab->p, a);
         HIP_TRY(launch_pass_post(model->k, grid, a, ctx->stream));
         HIP_TRY(launch_reduce_partials(scal, grid, 8, scal + (size_t)grid * 8, ctx->stream));
     }
@@ -807,7 +765,7 @@ extern "C" int ppca_llk(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model
                         double *per_sample_host) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     BufRef l;
     if (per_sample_host)
         if (int rc = dev_alloc(sizeof(double) * (size_t)ds->n, &l)) return rc;
@@ -827,7 +785,7 @@ extern "C" int ppca_infer(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *mod
                           double *covs_host) {
     if (!ctx || !states_host) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     const int k = model->k;
     BufRef st, cv;
     if (int rc = dev_alloc(sizeof(double) * (size_t)ds->n * k, &st)) return rc;
@@ -849,7 +807,7 @@ extern "C" int ppca_infer(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *mod
 static int recon_common(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, int mode, ppca_dataset **out) {
     if (!ctx || !out) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     auto nd = std::make_unique<ppca_dataset>();
     nd->ctx = ctx;
     nd->n = ds->n;
@@ -920,7 +878,7 @@ extern "C" int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *
     if (!ctx || !log_weights) return fail(PPCA_ERR_INVALID, "null argument");
     if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models, n_models)) return rc;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     const int64_t n = ds->n;
     if (n == 0) {  // mix.rs:164-166
         if (total_host) *total_host = 0.0;
@@ -950,7 +908,7 @@ extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *con
     if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models_in, n_models)) return rc;
     if (ds->n == 0) return fail(PPCA_ERR_EMPTY, "dataset is empty");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     const int64_t n = ds->n;
     const int nm = n_models;
     BufRef llk, u, lse;
@@ -998,7 +956,7 @@ extern "C" int ppca_mix_responsibilities_dev(ppca_ctx *ctx, ppca_dataset *ds, pp
     if (!ctx || !log_weights || !u_dev) return fail(PPCA_ERR_INVALID, "null argument");
     if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models, n_models)) return rc;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     const int64_t n = ds->n;
     if (n == 0) return PPCA_OK;
     BufRef llk, u, lse;
@@ -1011,7 +969,7 @@ extern "C" int ppca_mix_responsibilities_dev(ppca_ctx *ctx, ppca_dataset *ds, pp
 
 extern "C" int ppca_vector_max_dev(ppca_ctx *ctx, const double *v_dev, int64_t n, double *max_host) {
     if (!ctx || !v_dev || !max_host) return fail(PPCA_ERR_INVALID, "null argument");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     double *work = static_cast<double *>(ctx->work->p);
     HIP_TRY(launch_reduce_max(v_dev, n, work + 1025, work, ctx->stream));
     HIP_TRY(hipMemcpyAsync(max_host, work + 1025, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1021,7 +979,7 @@ extern "C" int ppca_vector_max_dev(ppca_ctx *ctx, const double *v_dev, int64_t n
 
 extern "C" int ppca_vector_sum_dev(ppca_ctx *ctx, const double *v_dev, const double *w_dev, int64_t n, double *sum_host) {
     if (!ctx || !v_dev || !sum_host) return fail(PPCA_ERR_INVALID, "null argument");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     double *work = static_cast<double *>(ctx->work->p);
     HIP_TRY(launch_reduce_sum(v_dev, w_dev, n, work + 1026, work, ctx->stream));
     HIP_TRY(hipMemcpyAsync(sum_host, work + 1026, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1031,7 +989,7 @@ extern "C" int ppca_vector_sum_dev(ppca_ctx *ctx, const double *v_dev, const dou
 
 extern "C" int ppca_vector_exp_shift_dev(ppca_ctx *ctx, const double *v_dev, double shift, int64_t n, double *out_dev) {
     if (!ctx || !v_dev || !out_dev) return fail(PPCA_ERR_INVALID, "null argument");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     double *work = static_cast<double *>(ctx->work->p);
     HIP_TRY(hipMemcpyAsync(work + 1025, &shift, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1045,7 +1003,7 @@ extern "C" int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model 
     if (mode < 0 || mode > 3) return fail(PPCA_ERR_INVALID, "mode must be 0..3");
     if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models, n_models)) return rc;
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     const int64_t n = ds->n;
     const int d = ds->d, nm = n_models;
     auto nd = std::make_unique<ppca_dataset>();
@@ -1094,9 +1052,37 @@ extern "C" int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model 
 }
 
 // ------------------------------------------------------------------ debug
+extern "C" int ppca_gram_engine(ppca_ctx *ctx, const ppca_model *model, int32_t *engine) {
+    if (!ctx || !model || !engine) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_path(model->d, model->k)) return rc;
+    USE_CTX(ctx);
+    if (ppca_path_kind(model->d, model->k) == 0) {
+        *engine = 1;  // the generic pipeline contracts on the fp64 MFMA
+        return PPCA_OK;
+    }
+    if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
+    PassArgs a{};
+    a.model = model->p();
+    a.d = model->d;
+    fused_qtab_layout(ctx->qtab->p, a);
+    int forced = -1;
+    HIP_TRY(launch_gram_guard(model->k, a, ctx->stream, &forced));
+    if (forced >= 0) {
+        *engine = forced;
+        return PPCA_OK;
+    }
+    int flags[8];
+    HIP_TRY(hipMemcpyAsync(flags, a.qflag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int unsafe = 0;
+    for (int t = 0; t < fused_gram_tiles(model->k); ++t) unsafe |= flags[t];
+    *engine = unsafe ? 1 : 0;
+    return PPCA_OK;
+}
+
 extern "C" int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const double *b4x16, double *out16x16) {
     if (!ctx || !a16x4 || !b4x16 || !out16x16) return fail(PPCA_ERR_INVALID, "null argument");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     BufRef buf;
     if (int rc = dev_alloc(sizeof(double) * (64 + 64 + 256), &buf)) return rc;
     double *p = static_cast<double *>(buf->p);
@@ -1110,7 +1096,7 @@ extern "C" int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const d
 
 extern "C" int ppca_debug_mfma_i8_probe(ppca_ctx *ctx, const int8_t *a_regs, const int8_t *b_regs, int32_t *out_regs) {
     if (!ctx || !a_regs || !b_regs || !out_regs) return fail(PPCA_ERR_INVALID, "null argument");
-    if (int rc = use_device(ctx)) return rc;
+    USE_CTX(ctx);
     BufRef buf;
     if (int rc = dev_alloc(1024 + 1024 + 1024, &buf)) return rc;
     char *p = static_cast<char *>(buf->p);

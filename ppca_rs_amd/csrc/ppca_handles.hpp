@@ -1,0 +1,85 @@
+// ppca_handles.hpp -- the opaque handles of include/ppca_hip.h and the small host helpers shared by the C-ABI
+// sources (ppca_capi.hip, ppca_comm.hip).  Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "../../include/ppca_hip.h"
+#include "ppca_internal.hpp"
+
+struct DevBuf {
+    void *p = nullptr;
+    bool owned = true;
+    int device = 0;
+    ~DevBuf() {
+        if (p && owned) (void)hipFree(p);
+    }
+};
+typedef std::shared_ptr<DevBuf> BufRef;
+
+struct ppca_ctx {
+    mutable std::recursive_mutex mu;  // see USE_CTX
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    bool timing = false;
+    int skip_llk = 0;  // internal: set around the mixture's component EM steps (PassArgs::no_llk)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    BufRef part;  // per-workgroup partial statistics
+    size_t part_cap = 0;
+    BufRef stats;  // scratch statistics buffer (em_step, em_step_sharded, stats_raw)
+    size_t stats_cap = 0;
+    int64_t stats_llk_at = -1;  // where the last EM step left the log-likelihood of its input model in `stats`
+    BufRef scal;  // post-pass scalars: [grid][8] partials + 8 reduced
+    size_t scal_cap = 0;
+    BufRef work;  // 2048 doubles for reductions
+    BufRef qtab;  // int8 Gram slice table + scales + guard flags of the model being processed
+    size_t qtab_cap = 0;
+    BufRef gws;   // workspace of the generic split pipeline
+    size_t gws_cap = 0;
+};
+
+struct ppca_dataset {
+    ppca_ctx *ctx = nullptr;
+    BufRef xbuf, wbuf;
+    const double *X = nullptr;
+    const double *w = nullptr;  // nullptr = all ones
+    int64_t n = 0;
+    int d = 0;
+};
+
+struct ppca_model {
+    ppca_ctx *ctx = nullptr;
+    int d = 0, k = 0;
+    BufRef buf;
+    double *p() const { return static_cast<double *>(buf->p); }
+};
+
+namespace ppca_host {
+// Records the message of the failure for ppca_last_error() on this thread and returns `code`.
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int dev_alloc(size_t bytes, BufRef *out);
+BufRef dev_borrow(const void *p);
+int ensure(BufRef &b, size_t &cap, size_t bytes);
+int use_device(const ppca_ctx *ctx);
+}  // namespace ppca_host
+
+#define HIP_TRY(expr)                                                                                              \
+    do {                                                                                                           \
+        hipError_t _e = (expr);                                                                                    \
+        if (_e != hipSuccess) return ppca_host::fail(PPCA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// Every entry point that touches a context's scratch (partials, statistics, scalars, slice table, events) or reads
+// results back holds the context's lock for its whole enqueue-and-read sequence: the reference's methods may be
+// called from several Python threads at once (src/python_bindings.rs:466-511 release the GIL; ctypes does too).
+// Across calls the single stream orders the reuse of the scratch.  Recursive: entry points build on each other.
+#define USE_CTX(c)                                            \
+    std::lock_guard<std::recursive_mutex> ctx_lock_((c)->mu); \
+    if (int rc_ = ppca_host::use_device(c)) return rc_

@@ -38,6 +38,8 @@ struct PassArgs {
     int recon_mode;       // 0 smooth, 1 extrapolate, 2 smoothed cov diag, 3 extrapolated cov diag
     signed char *qtab;    // int8 Gram slice table of the current model (written by the launcher's qprep)
     double *qscale;       // its 64 dequantisation multipliers
+    int *qflag;           // per column tile: 1 = the int8 form is not safe for this model (qprep's dynamic-range
+                          // guard) -> the fp64-Gram instantiation runs; nullptr = run unconditionally
     int no_llk;           // EM mode: the caller does not read SC_LLK (mixture component steps): skip the
                           // per-sample logarithm of the weighted path
     double *dbg;          // diagnostic builds (-DPPCA_PHASE_TIMING): [grid][4] phase cycle sums
@@ -46,7 +48,12 @@ struct PassArgs {
 // Number of workgroups the fused pass wants for n rows on a device with n_cu CUs.
 int fused_grid(int64_t n, int n_cu);
 size_t fused_lds_bytes(int k);
-size_t fused_qtab_bytes();  // device scratch the fused launchers need in PassArgs::qtab / qscale
+size_t fused_qtab_bytes();  // device scratch the fused launchers need in PassArgs::qtab / qscale / qflag
+void fused_qtab_layout(void *base, PassArgs &a);  // points the three at a buffer of fused_qtab_bytes()
+// Runs only the slice-table / guard kernel of a model (what every fused pass launches first).  *forced = 0 / 1 when
+// the environment pins the engine (int8 without guard / fp64), -1 when qflag decides.
+hipError_t launch_gram_guard(int k, const PassArgs &a, hipStream_t s, int *forced);
+int fused_gram_tiles(int k);  // number of qflag entries the guard writes for state size k
 // Launchers.  Return hipSuccess or the launch error.
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s);
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);

@@ -19,6 +19,7 @@
 //       accumulators persistent in registers across all tiles of the workgroup
 // and end with one deterministic per-workgroup partial that reduce_partials sums
 // in fixed order.  No atomics: results are bit-reproducible for a given grid.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -139,17 +140,46 @@ constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
 // (wave-level maximum first -- non-negative doubles order like their bit patterns -- then one LDS atomic per wave)
 // -> qscale.  Step 2, thread = (k-chunk, lane): 16 dims x one column, its 16 digits of every slice as one 16-byte
 // store per slice.  (Two launches before: a single-workgroup maximum over all 55 columns took 21 us per iteration.)
+//
+// Dynamic-range guard.  One scale per column means that a sample which masks the rows carrying the column maximum
+// gets a Gram summed from entries truncated at 2^(E_c - 55) each.  Per model (no knowledge of the masks) two
+// rigorous bounds are available, with eps = max_c 2^(E_c - 55), m' = observed rows with a non-zero c_j:
+//   forward:   |dG|_F <= K m' eps  and  lambda_min(M_i) >= sigma^2  =>  |dM^-1| / |M^-1| <= K d eps / sigma^2
+//   backward:  |G_i|_2 >= tr(G_i) / K >= m' r_min / K  (r_min = smallest non-zero |c_j|^2)
+//                                                      =>  |dG|_F / |G_i|_2 <= K^2 eps / r_min
+// The int8 Gram is used when the forward bound is below 1e-8 OR the backward bound is below 2^-40 (fp64
+// accumulation itself sits at ~2^-50 of |G_i|); otherwise -- or when a product is not finite / >= 1e300, which the
+// fixed-point form cannot carry -- qflag[tile] is raised and the launcher's fp64-MFMA instantiation of the pass
+// runs instead (both are enqueued, each returns at once unless the flag selects it: no host round trip).
+constexpr double QGUARD_FWD = 1.0e-8;
+constexpr double QGUARD_BWD = 9.094947017729282e-13;  // 2^-40
+
 template <int K>
-__global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, double *qscale, signed char *qtab) {
+__global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, double *qscale, signed char *qtab,
+                                                    int *qflag) {
     constexpr int KP = Cfg<K>::KP;
     __shared__ unsigned long long cmax[16];
     __shared__ double scale[16];
+    __shared__ unsigned long long rmin_bits;
+    __shared__ int bad;
     const int t = blockIdx.x, j = threadIdx.x;
     if (j < 16) cmax[j] = 0ull;
+    if (j == 0) {
+        rmin_bits = 0x7FF0000000000000ull;  // +inf: no non-zero row
+        bad = 0;
+    }
     __syncthreads();
     double cj[K];
 #pragma unroll
     for (int a = 0; a < K; ++a) cj[a] = (j < d) ? model[MODEL_HDR + (int64_t)j * K + a] : 0.0;
+    {
+        double rn = 0.0;
+#pragma unroll
+        for (int a = 0; a < K; ++a) rn += cj[a] * cj[a];
+        // non-negative doubles order like their bit patterns; NaN / inf rows are caught by the product test below
+        if (rn > 0.0 && rn < 1.0e300) atomicMin(&rmin_bits, (unsigned long long)__double_as_longlong(rn));
+    }
+    int notfin = 0;
     double q[16];
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
@@ -164,8 +194,12 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
             cb = (u == b) ? cj[u] : cb;
         }
         q[cc] = (c < KP) ? fabs(ca * cb) : 0.0;
-        if (!(q[cc] < 1.0e300)) q[cc] = 0.0;
+        if (!(q[cc] < 1.0e300)) {
+            q[cc] = 0.0;
+            notfin = 1;
+        }
     }
+    if (notfin) atomicOr(&bad, 1);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)  // sixteen independent butterflies per level: the shuffle latency overlaps
 #pragma unroll
@@ -183,8 +217,16 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
         const double sc = ldexp(1.0, e - (7 * QS - 2));
         scale[j] = sc;
         qscale[16 * t + j] = sc;
+        if (mx > 0.0) {
+            const double eps = 0.5 * sc;  // rounding bound of one entry: 2^(E_c - 55)
+            const double s2m = model[1], rmin = __longlong_as_double((long long)rmin_bits);
+            const bool fwd = (double)K * (double)d * eps <= QGUARD_FWD * s2m;
+            const bool bwd = (double)(K * K) * eps <= QGUARD_BWD * rmin;
+            if (!(fwd || bwd)) atomicOr(&bad, 1);
+        }
     }
     __syncthreads();
+    if (j == 0) qflag[t] = bad;
     const int lane = j & 63, kc = j >> 6;
     const int c = 16 * t + (lane & 15);
     int a = 0;
@@ -249,6 +291,12 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     double *xxs = sm + cfg::OFF_S;
     int *mcnt = reinterpret_cast<int *>(sm + cfg::OFF_S + B);
 
+    if (p.qflag) {  // Gram engine chosen per model by qprep's dynamic-range guard: exactly one of the two variants runs
+        int unsafe = 0;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) unsafe |= p.qflag[t];
+        if (GI8 == (unsafe != 0)) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bases stay in SGPRs
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1302,34 +1350,74 @@ size_t fused_lds_bytes(int k) {
     return 0;
 }
 
+// hipFuncSetAttribute is per device: remember which devices have seen it for this instantiation.
+template <int K, bool EM, int NW, bool GI8>
+static hipError_t pass_attr(size_t lds) {
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM, NW, GI8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
 template <int K, bool EM, int NW, bool GI8>
 static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
     const size_t lds = sizeof(double) * Cfg<K>::LDS_DOUBLES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM, NW, GI8>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    if constexpr (GI8) {
-        // slice table of the current model (device-side, no host sync): column maxima, then digits
-        hipLaunchKernelGGL((qprep_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab);
-    }
+    if (hipError_t e = pass_attr<K, EM, NW, GI8>(lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((pass_kernel<K, EM, NW, GI8>), dim3(grid), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 
-size_t fused_qtab_bytes() { return qtab_bytes<FUSED_MAX_K>() + 64 * sizeof(double); }
+size_t fused_qtab_bytes() { return qtab_bytes<FUSED_MAX_K>() + 72 * sizeof(double); }
+void fused_qtab_layout(void *base, PassArgs &a) {  // [64 scales | 8 doubles of guard flags | digit table]
+    a.qscale = static_cast<double *>(base);
+    a.qflag = reinterpret_cast<int *>(a.qscale + 64);
+    a.qtab = reinterpret_cast<signed char *>(a.qscale + 72);
+}
 
-// Gram engine: int8-sliced MFMA unless PPCA_GRAM_FP64=1.
-static bool gram_i8() {
-    static int v = -1;
-    if (v < 0) {
+// Gram engine of the 4-wave passes: 0 = int8-sliced MFMA behind the dynamic-range guard, with the fp64-MFMA
+// instantiation as its on-device fallback (default); 1 = fp64 MFMA always (PPCA_GRAM_FP64=1);
+// 2 = int8 without the guard (PPCA_GRAM_GUARD=0: measurements only).
+static int gram_mode() {
+    static const int v = [] {
         const char *e = getenv("PPCA_GRAM_FP64");
-        v = (e && atoi(e) == 1) ? 0 : 1;
+        if (e && atoi(e) == 1) return 1;
+        const char *g = getenv("PPCA_GRAM_GUARD");
+        if (g && atoi(g) == 0) return 2;
+        return 0;
+    }();
+    return v;
+}
+
+// Slice table + guard flags of the current model (device-side, no host sync), then the pass: the int8 variant and,
+// behind the guard, the fp64 variant -- each returns at once unless qflag selects it.
+template <int K, bool EM>
+static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
+#ifdef PPCA_DEV_K10
+    const int mode = 2;  // kernel-tuning builds instantiate the int8 variants only
+#else
+    const int mode = gram_mode();
+    if (mode == 1) {
+        a.qflag = nullptr;
+        return launch_pass_t<K, EM, 4, false>(grid, a, s);
     }
-    return v == 1;
+#endif
+    hipLaunchKernelGGL((qprep_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab, a.qflag);
+    if (mode == 2) {
+        a.qflag = nullptr;
+        return launch_pass_t<K, EM, 4, true>(grid, a, s);
+    }
+#ifdef PPCA_DEV_K10
+    return hipErrorInvalidValue;
+#else
+    if (hipError_t e = launch_pass_t<K, EM, 4, true>(grid, a, s); e != hipSuccess) return e;
+    return launch_pass_t<K, EM, 4, false>(grid, a, s);
+#endif
 }
 
 // Waves per workgroup of the EM pass: 4 (one per SIMD, 512 registers each).  PPCA_FUSED_WAVES=8 selects the
@@ -1337,11 +1425,10 @@ static bool gram_i8() {
 // end of round 1 -- the per-sample solve spills at 256 registers and both waves of a SIMD sit in the same phase, so
 // there is no MFMA time for the other's vector work to hide in.  PPCA_GRAM_FP64=1 (fp64-MFMA Gram, 4 waves): 240.
 static int em_waves() {
-    static int nw = 0;
-    if (nw == 0) {
+    static const int nw = [] {
         const char *e = getenv("PPCA_FUSED_WAVES");
-        nw = (e && atoi(e) == 8) ? 8 : 4;
-    }
+        return (e && atoi(e) == 8) ? 8 : 4;
+    }();
     return nw;
 }
 
@@ -1371,30 +1458,37 @@ static int em_waves() {
 
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
 #ifdef PPCA_DEV_K10
-    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4, true>(grid, a, s)));
+    PPCA_DISPATCH_K(k, return (launch_pass_guarded<KK, true>(grid, a, s)));
 #else
     if (em_waves() == 8) {
-        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 8, false>(grid, a, s)));
-    } else if (gram_i8()) {
-        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4, true>(grid, a, s)));
+        PassArgs b = a;
+        b.qflag = nullptr;
+        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 8, false>(grid, b, s)));
     } else {
-        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 4, false>(grid, a, s)));
+        PPCA_DISPATCH_K(k, return (launch_pass_guarded<KK, true>(grid, a, s)));
     }
 #endif
     return hipErrorInvalidValue;
 }
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s) {
-#ifdef PPCA_DEV_K10
-    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, true>(grid, a, s)));
-#else
-    if (gram_i8()) {
-        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, true>(grid, a, s)));
-    } else {
-        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, false>(grid, a, s)));
-    }
-#endif
+    PPCA_DISPATCH_K(k, return (launch_pass_guarded<KK, false>(grid, a, s)));
     return hipErrorInvalidValue;
 }
+
+hipError_t launch_gram_guard(int k, const PassArgs &a, hipStream_t s, int *forced) {
+#ifdef PPCA_DEV_K10
+    *forced = 0;
+    return hipSuccess;
+#else
+    const int mode = gram_mode();
+    *forced = mode == 1 ? 1 : (mode == 2 ? 0 : -1);
+    if (mode != 0) return hipSuccess;
+    PPCA_DISPATCH_K(k, hipLaunchKernelGGL((qprep_kernel<KK>), dim3(Cfg<KK>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale,
+                                          a.qtab, a.qflag));
+    return hipGetLastError();
+#endif
+}
+int fused_gram_tiles(int k) { return (k * (k + 1) / 2 + 15) / 16; }
 
 hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s) {
     int blocks = (int)((len + 63) / 64);

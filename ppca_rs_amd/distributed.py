@@ -62,31 +62,90 @@ def allreduce_finalize_host(model: PPCAModel, local_stats: np.ndarray, prior: Op
     return finalize_host(model, red, prior), llk
 
 
+class Communicator:
+    """ppca_comm: the library's own RCCL communicator over the ranks (one rank per GPU), bound to a context.
+
+    `Communicator.from_torch(ctx)` takes rank / world size from the initialised torch.distributed process group and
+    ships rank 0's 128-byte unique id through it (any backend: the id travels as a pickled object); the data path
+    -- the all-reduce of the statistics buffer -- then runs inside the library on the context stream."""
+
+    def __init__(self, ctx: _lib.Context, n_ranks: int, rank: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        self.ctx, self.n_ranks, self.rank = ctx, n_ranks, rank
+        h = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        check(lib().ppca_comm_create(ctx.handle, n_ranks, rank, buf, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        check(lib().ppca_comm_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def backend() -> str:
+        return lib().ppca_comm_backend().decode()
+
+    @classmethod
+    def from_torch(cls, ctx: _lib.Context, group=None) -> "Communicator":
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return cls(ctx, 1, 0, cls.unique_id())
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(ctx, world, rank, box[0])
+
+    def allreduce(self, ptr_dev: int, n: int, op: str = "sum") -> None:
+        check(lib().ppca_comm_allreduce(self.h, C.c_void_p(ptr_dev), n, {"sum": 0, "max": 1}[op]))
+
+    def close(self) -> None:
+        if self.h:
+            lib().ppca_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedEM:
     """Device flavour: holds this rank's shard and a ping-pong pair of device models;
-    `step()` enqueues pass -> all-reduce -> finalise on ONE dedicated torch stream, which is
-    also the stream the library launches on, without any host synchronisation.  (A dedicated
+    `step()` enqueues pass -> all-reduce -> finalise on ONE dedicated stream, without any host
+    synchronisation.  With `comm` (a Communicator) the whole step is ONE C-ABI call,
+    ppca_em_step_sharded, and the collective is the library's own RCCL all-reduce; without it the
+    collective is torch.distributed's (backend "nccl" = RCCL for device buffers, "gloo" stages through
+    the host) on a dedicated torch stream that the library is pointed at.  (A dedicated
     stream, not torch's default one: the legacy default stream has handle 0, which the C-ABI
     reads as "create your own stream" -- the collective would then not be ordered after the
     kernels.)"""
 
-    def __init__(self, shard: Dataset, start: PPCAModel, prior: Optional[Prior] = None, group=None):
+    def __init__(self, shard: Dataset, start: PPCAModel, prior: Optional[Prior] = None, group=None, comm=None):
         import torch
 
         self.torch = torch
-        self.shard, self.prior, self.group = shard, prior, group
+        self.shard, self.prior, self.group, self.comm = shard, prior, group, comm
         self.ctx = shard._ctx
         self.d, self.k = start.output_size, start.state_size
         self.stream = torch.cuda.Stream()
         assert self.stream.cuda_stream != 0
         with torch.cuda.stream(self.stream):
             self.stats = torch.zeros(stats_len(self.d, self.k), dtype=torch.float64, device="cuda")
-        self.cur = start._device(self.ctx)
+        # Two PRIVATE device models: the ping-pong must never write into the cached device copy of the caller's
+        # (immutable) start model.
+        h = C.c_void_p()
+        check(lib().ppca_model_create(self.ctx.handle, self.d, self.k, start.isotropic_noise, ptr(start._c),
+                                      ptr(start._mean), C.byref(h)))
+        self.cur = _DevModel(h)
         h = C.c_void_p()
         check(lib().ppca_model_alloc(self.ctx.handle, self.d, self.k, C.byref(h)))
         self.nxt = _DevModel(h)
         self._pref, self._keep = _prior_ref(prior)
-        self._start = start  # keeps the first device model alive
         torch.cuda.synchronize()
         self.ctx.set_stream(self.stream.cuda_stream)
 
@@ -94,6 +153,11 @@ class ShardedEM:
         import torch.distributed as dist
 
         torch = self.torch
+        if self.comm is not None:
+            # statistics in the context's scratch; llk_of_previous() re-reads them from there
+            check(lib().ppca_em_step_sharded(self.comm.h, self.shard._h, self.cur.h, self._pref, self.nxt.h, None))
+            self.cur, self.nxt = self.nxt, self.cur
+            return
         with torch.cuda.stream(self.stream):
             check(lib().ppca_em_accumulate(self.ctx.handle, self.shard._h, self.cur.h, C.c_void_p(self.stats.data_ptr())))
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
@@ -107,6 +171,10 @@ class ShardedEM:
 
     def llk_of_previous(self) -> float:
         """llk of the model that entered the last step() (synchronises)."""
+        if self.comm is not None:
+            v = C.c_double(0.0)
+            check(lib().ppca_em_last_llk(self.ctx.handle, C.byref(v)))
+            return v.value
         self.stream.synchronize()
         return float(self.stats[stats_len(self.d, self.k) - 8 + 2].item())
 

@@ -74,7 +74,32 @@ def mix_case(name, n, d, k, nm, seed, iters=3):
     print(name, "llk", llks)
 
 
+def cfg5_case(name, iters=2):
+    """BASELINE config 5 at its own shape (K = 8, d = 256, k = 10, 30 % masked, weighted), oracle-sized N.  The
+    inputs are regenerated from a seed (tests/golden/inputs.py); the fixture holds their checksum and the oracle's
+    outputs: per-sample mixture llks, log posteriors, and `iters` weighted mixture EM iterations (mix.rs:137-189,
+    :281-337)."""
+    from inputs import cfg5_inputs, digest
+
+    x, w, sig, cs, ms, lw = cfg5_inputs()
+    out = dict(digest=np.array(digest(x, w, sig, cs, ms, lw)), llks=o.mix_llks(x, sig, cs, ms, lw),
+               log_posterior=o.mix_infer_cluster(x, sig, cs, ms, lw))
+    sigs, css, mss, lws, llks = [], [], [], [], []
+    for _ in range(iters):
+        llks.append(float((o.mix_llks(x, sig, cs, ms, lw) * w).sum()))
+        sig, cs, ms, lw = o.mix_iterate(x, sig, cs, ms, lw, w)
+        sigs.append(sig); css.append(cs); mss.append(ms); lws.append(lw)
+    out["it_sigma"], out["it_c"], out["it_mean"], out["it_lw"], out["it_llk"] = map(np.array, (sigs, css, mss, lws, llks))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "llk", llks)
+
+
 if __name__ == "__main__":
+    sys.path.insert(0, HERE)
+    if "--only-cfg5" in sys.argv:
+        cfg5_case("cfg5_d256_k10_m8")
+        sys.exit(0)
+    cfg5_case("cfg5_d256_k10_m8")
     mix_case("mix_d16_k3_m3", 360, 16, 3, 3, 71)
     case("toy_d3_k2", 100, 3, 2, 0.2, 11, iters=5)
     case("small_d12_k3", 300, 12, 3, 0.3, 21, iters=3)

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-              if not os.path.basename(p).startswith("mix_"))
+              if not os.path.basename(p).startswith(("mix_", "cfg5_")))
 GOLD_MIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mix_*.npz")))
 RTOL = 1e-5  # north_star tolerance
 
@@ -588,3 +588,249 @@ def test_sharded_mixture_two_ranks_on_one_gpu():
                         "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "tools", "mix_sharded_check.py")],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "sharded mixture OK" in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])
+
+
+# --------------------------------------------------------------------------- round 2
+def _cfg5_fixture():
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from inputs import cfg5_inputs, digest
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg5_d256_k10_m8.npz"))
+    inp = cfg5_inputs()
+    assert digest(*inp) == str(g["digest"])
+    return g, inp
+
+
+def test_config5_shape_mixture(P):
+    """BASELINE config 5 at ITS shape -- 8 components, d = 256, state_size = 10, 30 % masked, non-uniform sample
+    weights (the weighted branch of pass_kernel<10, ...> with the per-sample logarithm, and the no_llk component
+    steps) -- against the committed oracle fixture: mixture llks, log posteriors, two weighted EM iterations."""
+    g, (x, w, sig, cs, ms, lw) = _cfg5_fixture()
+    ds = P.Dataset(x, w)
+    mix = P.PPCAMix([P.PPCAModel(sig[c], cs[c], ms[c]) for c in range(len(sig))], lw)
+    assert _rel(mix.llks(ds), g["llks"]) < 1e-10
+    lp = mix.infer_cluster(ds)
+    assert np.abs(np.exp(lp) - np.exp(g["log_posterior"])).max() < 1e-9
+    soft = np.exp(g["log_posterior"]).max(axis=1) < 0.99
+    assert soft.mean() > 0.05 and np.abs(lp[soft] - g["log_posterior"][soft]).max() < 1e-7
+    for it in range(len(g["it_llk"])):
+        mix, llk = mix.iterate_with_llk(ds)
+        assert abs(llk - g["it_llk"][it]) < 1e-9 * abs(g["it_llk"][it]), it
+        for c, mdl in enumerate(mix.models):
+            assert abs(mdl.isotropic_noise - g["it_sigma"][it][c]) < RTOL * 1e-2 * g["it_sigma"][it][c], (it, c)
+            assert _rel(mdl.transform, g["it_c"][it][c]) < RTOL * 1e-1, (it, c)
+            assert _rel(mdl.mean, g["it_mean"][it][c]) < RTOL * 1e-1, (it, c)
+        assert np.abs(np.exp(mix.log_weights) - np.exp(g["it_lw"][it])).max() < 1e-9, it
+
+
+def _engine(P, ds, m):
+    from ppca_rs_amd import _lib
+
+    e = C.c_int32(-1)
+    _lib.check(_lib.lib().ppca_gram_engine(ds._ctx.handle, m._device(ds._ctx).h, C.byref(e)))
+    return e.value
+
+
+def test_int8_gram_dynamic_range_guard(P, oracle):
+    """The int8-sliced Gram keeps 54 bits below each column maximum of vech(c c^T); when a sample masks the rows that
+    set the maximum, its Gram would be summed from truncated entries.  qprep's guard must send such models to the
+    fp64-MFMA Gram on the device (output_covariance.rs:57-70 computes C_o^T C_o in f64), and keep the benign ones on
+    the int8 engine."""
+    rng = np.random.default_rng(77)
+    d, k, n = 256, 10, 640
+    big = np.sort(rng.choice(d, 200, replace=False))
+    small = np.setdiff1d(np.arange(d), big)
+    # benign model of the headline shape: int8
+    c0, mu = rng.standard_normal((d, k)), 0.1 * rng.standard_normal(d)
+    x0, _, _ = oracle.synth(n, d, k, 0.3, 4242)
+    assert _engine(P, P.Dataset(x0), P.PPCAModel(0.1, c0, mu)) == 0
+    # (a) rows of C spanning 1e8, the 200 large ones masked in EVERY sample (a model applied to data without those
+    # dims): every sample's Gram is O(1) under a column maximum of O(1e17) -- all digits of the int8 form fall off.
+    # The oracle is meaningful here (|G| / sigma^2 is moderate): statistics, llks, posteriors, one EM step.
+    scale = np.ones(d)
+    scale[big] = 1.0e8
+    c = rng.standard_normal((d, k)) * scale[:, None]
+    s = 0.05
+    z = rng.standard_normal((n, k))
+    x = z @ c.T + mu + s * rng.standard_normal((n, d))
+    x[rng.random((n, d)) < 0.3] = np.nan
+    xa = x.copy()
+    xa[:, big] = np.nan
+    w = rng.uniform(0.5, 1.5, n)
+    ds, m = P.Dataset(xa, w), P.PPCAModel(s, c, mu)
+    assert _engine(P, ds, m) == 1
+    from ppca_rs_amd import _lib
+
+    L = _lib.lib().ppca_stats_len(d, k)
+    got = np.empty(L)
+    _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
+    want = oracle.stats(xa, s, c, mu, w)
+    kp = k * (k + 1) // 2
+    bounds = [0, d * k, d * k + d * kp, 2 * d * k + d * kp, 2 * d * k + d * kp + d, 2 * d * k + d * kp + 2 * d, L]
+    for name, a, b in zip(["cross", "S", "U", "sumx", "totals", "scalars"], bounds[:-1], bounds[1:]):
+        assert _rel(got[a:b], want[a:b]) < 1e-9, name
+    assert _rel(m.llks(ds), oracle.llks(xa, s, c, mu)) < 1e-9
+    st, cv = oracle.infer(xa, s, c, mu)
+    inf = m.infer(ds)
+    assert _rel(inf.states(), st) < 1e-9 and _rel(np.array(inf.covariances()), cv) < 1e-9
+    new, llk = m.iterate_with_llk(ds)
+    s1, c1, m1 = oracle.iterate(xa, s, c, mu, w)
+    assert abs(llk - oracle.llk(xa, s, c, mu, w)) < 1e-9 * abs(llk)
+    assert abs(new.isotropic_noise - s1) < 1e-8 * s1 and _rel(new.transform[small], c1[small]) < 1e-8
+    np.testing.assert_array_equal(new.transform[big], c[big])  # empty dimensions keep their rows
+    # (b) the large rows masked in HALF the samples: posterior means against a long-double dense evaluation (the
+    # oracle's subtractive Woodbury form is void at |G| / sigma^2 ~ 1e21)
+    xb = x.copy()
+    half = np.arange(n) % 2 == 0
+    xb[np.ix_(half, big)] = np.nan
+    dsb = P.Dataset(xb)
+    assert _engine(P, dsb, m) == 1
+    zs = m.infer(dsb).states()
+    ld = np.longdouble
+    worst = 0.0
+    for i in list(range(0, 40)) + list(range(n - 40, n)):
+        o = np.isfinite(xb[i])
+        co = c[o].astype(ld)
+        M = co.T @ co + ld(s) ** 2 * np.eye(k, dtype=ld)
+        b = co.T @ (xb[i, o] - mu[o]).astype(ld)
+        Lc = np.zeros((k, k), dtype=ld)  # long-double Cholesky (numpy.linalg has no extended precision)
+        for a in range(k):
+            for bb in range(a + 1):
+                v = M[a, bb] - (Lc[a, :bb] * Lc[bb, :bb]).sum()
+                Lc[a, bb] = np.sqrt(v) if a == bb else v / Lc[bb, bb]
+        y = np.zeros(k, dtype=ld)
+        for a in range(k):
+            y[a] = (b[a] - (Lc[a, :a] * y[:a]).sum()) / Lc[a, a]
+        zz = np.zeros(k, dtype=ld)
+        for a in reversed(range(k)):
+            zz[a] = (y[a] - (Lc[a + 1:, a] * zz[a + 1:]).sum()) / Lc[a, a]
+        worst = max(worst, float(np.abs(zs[i] - zz.astype(np.float64)).max() / max(np.abs(zz).max(), 1e-300)))
+    assert worst < 1e-9, worst
+    # (c) a non-finite product cannot be carried by the fixed-point form: fp64 engine, and the NaN propagates
+    cn = c0.copy()
+    cn[3, 2] = np.inf
+    mn = P.PPCAModel(0.5, cn, mu)
+    assert _engine(P, P.Dataset(x0), mn) == 1
+    assert not np.isfinite(mn.llk(P.Dataset(x0)))
+
+
+def test_library_rccl_communicator_single_rank(P, oracle):
+    """The collective behind the C-ABI (ppca_comm_*, ppca_em_step_sharded, ppca_em_step_group) through RCCL with a
+    clique of ONE rank -- the only size a 1-GPU box admits (RCCL refuses two ranks on one device): the sharded step
+    must equal the plain one bit for bit, the sum / max all-reduces must be identities."""
+    import torch
+
+    from ppca_rs_amd import _lib
+    from ppca_rs_amd.distributed import Communicator, ShardedEM
+
+    assert Communicator.backend().startswith("rccl"), Communicator.backend()
+    ctx = _lib.default_context()
+    comm = Communicator(ctx, 1, 0, Communicator.unique_id())
+    x, _, _ = oracle.synth(3000, 256, 10, 0.3, 91)
+    rng = np.random.default_rng(2)
+    start = P.PPCAModel(1.0, rng.standard_normal((256, 10)), np.zeros(256))
+    ds = P.Dataset(x)
+    want, want_llk = start.iterate_with_llk(ds)
+    em = ShardedEM(ds, start, comm=comm)
+    em.step()
+    got = em.model()
+    assert em.llk_of_previous() == want_llk
+    np.testing.assert_array_equal(got.transform, want.transform)
+    np.testing.assert_array_equal(got.mean, want.mean)
+    assert got.isotropic_noise == want.isotropic_noise
+    em.step()
+    want2 = want.iterate(ds)
+    np.testing.assert_array_equal(em.model().transform, want2.transform)
+    em.close()
+    t = torch.arange(1000, dtype=torch.float64, device="cuda") - 3.5
+    for op in ("sum", "max"):
+        u = t.clone()
+        comm.allreduce(u.data_ptr(), u.numel(), op)
+        ctx.synchronize()
+        assert torch.equal(u, t)
+    # one thread, a group of one device
+    lib = _lib.lib()
+    comms = (C.c_void_p * 1)()
+    ctxs = (C.c_void_p * 1)(ctx.handle)
+    _lib.check(lib.ppca_comm_create_all(ctxs, 1, comms))
+    out = C.c_void_p()
+    _lib.check(lib.ppca_model_alloc(ctx.handle, 256, 10, C.byref(out)))
+    llk = C.c_double(0.0)
+    shards, mins, mouts = (C.c_void_p * 1)(ds._h), (C.c_void_p * 1)(start._device(ctx).h), (C.c_void_p * 1)(out)
+    _lib.check(lib.ppca_em_step_group(comms, 1, shards, mins, None, mouts, C.byref(llk)))
+    sig = C.c_double(0.0)
+    cc, mm = np.empty((256, 10)), np.empty(256)
+    _lib.check(lib.ppca_model_download(out, C.byref(sig), _lib.ptr(cc), _lib.ptr(mm)))
+    assert llk.value == want_llk and sig.value == want.isotropic_noise
+    np.testing.assert_array_equal(cc, want.transform)
+    lib.ppca_model_free(out)
+    lib.ppca_comm_destroy(comms[0])
+    comm.close()
+
+
+def test_rccl_two_ranks_when_two_gpus(tmp_path):
+    """bench.py --gpus 2 started as a plain process: it must spawn its own ranks, run the all-reduce over RCCL
+    (the library's communicator), and reach the single-rank model.  Skipped on a 1-GPU box."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--samples", "200000", "--no-cpu"]
+    one, two, three = (str(tmp_path / f) for f in ("one.npz", "two.npz", "three.npz"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for gpus, dump, extra in ((1, one, []), (2, two, ["--collective", "capi"]), (2, three, ["--collective", "torch"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--dump-model", dump] + common + extra,
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        import json
+
+        assert json.loads(line)["n_gpus"] == gpus
+    a = np.load(one)
+    for other in (two, three):
+        b = np.load(other)
+        assert abs(a["sigma"] - b["sigma"]) < 1e-10 * a["sigma"] and _rel(b["transform"], a["transform"]) < 1e-9
+
+
+def test_concurrent_calls_on_one_context(P, oracle):
+    """The reference's methods release the GIL (src/python_bindings.rs:466-511) and may be called from several
+    threads; ctypes drops the GIL too, so four threads hammer ONE context with different models (llk, iterate,
+    infer, extrapolate) and must get exactly the serial results."""
+    import threading
+
+    x, _, _ = oracle.synth(20000, 256, 10, 0.3, 17)
+    ds = P.Dataset(x)
+    rng = np.random.default_rng(3)
+    models = [P.PPCAModel(0.5 + 0.2 * i, rng.standard_normal((256, 10)), 0.1 * rng.standard_normal(256)) for i in range(4)]
+
+    def work(m):
+        new, llk = m.iterate_with_llk(ds)
+        return (m.llk(ds), llk, new.transform.copy(), new.isotropic_noise, m.infer(ds).states()[:50].copy(),
+                m.extrapolate(ds._slice(0, 64)).numpy())
+
+    serial = [work(m) for m in models]
+    results, errors = [None] * 4, []
+
+    def run(i):
+        try:
+            for _ in range(6):
+                results[i] = work(models[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, want in zip(results, serial):
+        assert got[0] == want[0] and got[1] == want[1] and got[3] == want[3]
+        for a, b in zip((got[2], got[4], got[5]), (want[2], want[4], want[5])):
+            np.testing.assert_array_equal(a, b)

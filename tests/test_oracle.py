@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-              if not os.path.basename(p).startswith("mix_"))
+              if not os.path.basename(p).startswith(("mix_", "cfg5_")))
 GOLD_MIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mix_*.npz")))
 C_TOY = np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]])  # ppca_model.rs:647-656
 
@@ -172,6 +172,32 @@ def test_golden_mixture_vectors(oracle, path):
     for key in ("log_posterior", "state", "covariance", "smooth", "extrapolate", "smooth_covariance_diagonal",
                 "extrapolate_covariance_diagonal"):
         np.testing.assert_allclose(inf[key], g["inf_" + key], rtol=1e-10, atol=1e-12)
+    for it in range(len(g["it_llk"])):
+        assert abs(float((oracle.mix_llks(x, sig, cs, ms, lw) * w).sum()) - g["it_llk"][it]) < 1e-10 * abs(g["it_llk"][it])
+        sig, cs, ms, lw = oracle.mix_iterate(x, sig, cs, ms, lw, w)
+        np.testing.assert_allclose(sig, g["it_sigma"][it], rtol=1e-10)
+        np.testing.assert_allclose(cs, g["it_c"][it], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(lw, g["it_lw"][it], rtol=1e-10, atol=1e-13)
+
+
+def _cfg5():
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from inputs import cfg5_inputs, digest
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg5_d256_k10_m8.npz"))
+    inp = cfg5_inputs()
+    assert digest(*inp) == str(g["digest"]), "tests/golden/inputs.py no longer regenerates the fixture's inputs"
+    return g, inp
+
+
+def test_config5_fixture_is_what_the_oracle_computes(oracle):
+    """BASELINE config 5 at its own shape (K = 8, d = 256, k = 10, weighted): the committed fixture (inputs
+    regenerated from a seed, checksum checked) against the oracle, tests/golden/make_golden.py::cfg5_case."""
+    g, (x, w, sig, cs, ms, lw) = _cfg5()
+    np.testing.assert_allclose(oracle.mix_llks(x, sig, cs, ms, lw), g["llks"], rtol=1e-12)
+    np.testing.assert_allclose(oracle.mix_infer_cluster(x, sig, cs, ms, lw), g["log_posterior"], rtol=1e-10, atol=1e-10)
     for it in range(len(g["it_llk"])):
         assert abs(float((oracle.mix_llks(x, sig, cs, ms, lw) * w).sum()) - g["it_llk"][it]) < 1e-10 * abs(g["it_llk"][it])
         sig, cs, ms, lw = oracle.mix_iterate(x, sig, cs, ms, lw, w)
