@@ -124,6 +124,29 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _share_torch_hip_runtime() -> None:
+    """A PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64 / librccl.  If this library were bound to
+    /opt/rocm's runtime and torch were imported later, the process would hold TWO HIP runtimes: torch streams handed
+    to ppca_ctx_set_stream, and torch's RCCL, would belong to the other one.  So when a torch wheel with a bundled
+    runtime is installed, that runtime is loaded first (by path, without importing torch) and libppca_hip.so binds
+    to it through the common soname -- the configuration bench.py always ran in.  PPCA_SYSTEM_HIP=1 opts out."""
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("PPCA_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def lib():
     """The loaded shared library (raises ImportError loudly when it was not built)."""
     global _lib
@@ -135,6 +158,7 @@ def lib():
                         f"{LIB_PATH} is missing: build the HIP extension with `python -m ppca_rs_amd.build` "
                         "(there is no CPU fallback)"
                     )
+                _share_torch_hip_runtime()
                 handle = C.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(handle, name)

@@ -40,14 +40,18 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: 
     hipcc = _hipcc()
     objs = []
     procs = []
+    headers = [os.path.join(CSRC, f) for f in DEPS if f not in SOURCES]
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".diag.o" if extra_flags else ".o"))
+        objs.append(obj)
+        newest = max(os.path.getmtime(f) for f in [os.path.join(CSRC, src)] + headers)
+        if not force and not extra_flags and os.path.exists(obj) and os.path.getmtime(obj) > newest:
+            continue  # this object is current: only what changed is recompiled (the kernels take ~2 minutes)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra_flags, "-c", os.path.join(CSRC, src),
                "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((subprocess.Popen(cmd), cmd))
-        objs.append(obj)
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))

@@ -35,7 +35,10 @@ struct Rccl {
 };
 
 // A library that is already in the process (torch ships and loads its own librccl) is reused; otherwise the
-// loader's search path, then the ROCm default.  PPCA_RCCL_LIB overrides.
+// loader's search path, then the ROCm default.  PPCA_RCCL_LIB overrides.  A candidate is accepted only if it runs
+// on the SAME HIP runtime as this library: a PyTorch wheel bundles its own libamdhip64 next to its librccl, and
+// depending on the import order this library is bound either to that one or to /opt/rocm's -- streams and events
+// of one runtime mean nothing to the other.
 const Rccl &rccl() {
     static Rccl api;
     static std::once_flag once;
@@ -46,11 +49,21 @@ const Rccl &rccl() {
         for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
             tries.push_back({n, RTLD_NOW | RTLD_GLOBAL});
         void *h = nullptr;
+        void *const my_hip = reinterpret_cast<void *>(&hipStreamSynchronize);
         for (auto &t : tries) {
             h = dlopen(t.first.c_str(), t.second);
             if (h) {
-                api.origin = t.first + ((t.second & RTLD_NOLOAD) ? " (already loaded)" : "");
-                break;
+                // dlsym on a handle searches the library's dependency tree: the HIP runtime THIS librccl calls into
+                void *its_hip = dlsym(h, "hipStreamSynchronize");
+                if (its_hip == my_hip) {
+                    Dl_info info;
+                    void *probe = dlsym(h, "ncclAllReduce");
+                    api.origin = (probe && dladdr(probe, &info) && info.dli_fname) ? info.dli_fname : t.first;
+                    break;
+                }
+                api.error += t.first + " (bound to another HIP runtime); ";
+                h = nullptr;
+                continue;
             }
             api.error += t.first + "; ";
         }
