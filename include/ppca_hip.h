@@ -237,7 +237,7 @@ int ppca_em_step_group(ppca_comm *const *comms, int32_t n, ppca_dataset *const *
 /* PPCAMix::iterate_with_prior mix.rs:281-337 on one GPU: per-sample
  * responsibilities (log-softmax of llk_c + log pi_c, :283-295), per-component
  * weighted EM step (:297-330), new log-weights (:335).  models_in/out: n_models
- * handles of equal (d, k).  llk_in (nullable): mixture log-likelihood of the input
+ * handles of one output size d; state sizes may differ per component (mix.rs:50-71).  llk_in (nullable): mixture log-likelihood of the input
  * (PPCAMix::llk :162-174).  Samples with weight <= 0 contribute nothing
  * (documented divergence from :304-309/:326). */
 int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models_in, const double *log_weights_in,

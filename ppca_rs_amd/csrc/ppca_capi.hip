@@ -838,11 +838,10 @@ extern "C" int ppca_covariance_diagonal(ppca_ctx *ctx, ppca_dataset *ds, const p
 // ------------------------------------------------------------------ mixture
 static int mix_check(ppca_dataset *ds, ppca_model *const *models, int32_t nm) {
     if (!ds || !models || nm < 1) return fail(PPCA_ERR_INVALID, "bad mixture arguments");
-    for (int c = 0; c < nm; ++c) {
+    // components may have different state sizes (mix.rs:50-71, state_sizes :91): every pass below runs per
+    // component on that component's own instantiation
+    for (int c = 0; c < nm; ++c)
         if (int rc = check_pair(ds, models[c])) return rc;
-        if (models[c]->k != models[0]->k)
-            return fail(PPCA_ERR_UNSUPPORTED, "mixture components must share one state size");
-    }
     return PPCA_OK;
 }
 

@@ -835,3 +835,35 @@ def test_concurrent_calls_on_one_context(P, oracle):
         assert got[0] == want[0] and got[1] == want[1] and got[3] == want[3]
         for a, b in zip((got[2], got[4], got[5]), (want[2], want[4], want[5])):
             np.testing.assert_array_equal(a, b)
+
+
+def test_mixture_with_different_state_sizes(P):
+    """mix.rs:50-71 admits components of different state sizes (state_sizes, :91): k = (2, 4, 12) here -- two fused
+    instantiations and the generic pipeline in one mixture -- against the second restatement
+    (oracle/restate_numpy.py, mix.rs:281-337), weighted."""
+    from oracle import restate_numpy as R
+
+    rng = np.random.default_rng(23)
+    n, d, ks = 160, 14, (2, 4, 12)
+    x = rng.standard_normal((n, 3)) @ rng.standard_normal((3, d)) + 0.4 * rng.standard_normal((n, d))
+    x[rng.random((n, d)) < 0.25] = np.nan
+    w = rng.uniform(0.5, 1.5, n)
+    sig = [0.9, 1.1, 0.7]
+    cs = [0.6 * rng.standard_normal((d, k)) for k in ks]
+    ms = [0.3 * rng.standard_normal(d) for _ in ks]
+    lw = np.log(np.array([0.2, 0.5, 0.3]))
+    ds = P.Dataset(x, w)
+    mix = P.PPCAMix([P.PPCAModel(s, c, m) for s, c, m in zip(sig, cs, ms)], lw)
+    assert mix.state_sizes == list(ks)
+    comp = np.stack([R.llks(x, s, c, m) for s, c, m in zip(sig, cs, ms)], axis=1) + lw
+    want_llks = np.log(np.exp(comp - comp.max(1, keepdims=True)).sum(1)) + comp.max(1)
+    assert _rel(mix.llks(ds), want_llks) < 1e-9
+    for _ in range(2):
+        s1, c1, m1, lw1 = R.mix_iterate(x, np.array(sig), cs, ms, lw, w)
+        mix = mix.iterate(ds)
+        for c_, mdl in enumerate(mix.models):
+            assert abs(mdl.isotropic_noise - s1[c_]) < 1e-7 * s1[c_]
+            assert _rel(mdl.transform, c1[c_]) < 1e-6 and _rel(mdl.mean, m1[c_]) < 1e-6
+        assert _rel(mix.log_weights, lw1) < 1e-8
+        sig, cs, ms, lw = list(s1), c1, m1, lw1
+    assert mix.smooth(ds).numpy().shape == x.shape and mix.infer(ds).posteriors().shape == (n, 3)

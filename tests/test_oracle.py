@@ -204,3 +204,84 @@ def test_config5_fixture_is_what_the_oracle_computes(oracle):
         np.testing.assert_allclose(sig, g["it_sigma"][it], rtol=1e-10)
         np.testing.assert_allclose(cs, g["it_c"][it], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(lw, g["it_lw"][it], rtol=1e-10, atol=1e-13)
+
+
+# --------------------------------------------------------------------------- second restatement (round 2)
+def _restate():
+    from oracle import restate_numpy
+
+    return restate_numpy
+
+
+def _case(seed, n=70, d=9, k=3, mask=0.3):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, k)) @ rng.standard_normal((k, d)) + 0.3 * rng.standard_normal((n, d)) + rng.standard_normal(d)
+    x[rng.random((n, d)) < mask] = np.nan
+    x[4, :] = np.nan   # an all-masked sample
+    x[:, 5] = np.nan   # an empty dimension: its row of C and its mean are kept
+    return x, rng.uniform(0.3, 2.0, n), 0.8, rng.standard_normal((d, k)), 0.2 * rng.standard_normal(d), rng
+
+
+def test_closed_form_em_step(oracle):
+    """A hand-derivable EM step (ppca_model.rs:277-393): d = 2, k = 1, C = (1, 2)^T, sigma = 1, mean = 0, two fully
+    observed samples x1 = (1, 0), x2 = (0, 3).  M = 6, z = (1/6, 1), Sigma = 1/6, P = (7/36, 7/6), S = 49/36,
+    cross = (1/6, 3)  =>  C' = (6/49, 108/49); deviations (5/6, -1/3), (-1, 1), square_error 2 * 5/6
+    =>  sigma'^2 = (5/3 + 29/36 + 2) / 4 = 161/144; mean' = (-1/12, 1/3).  Both restatements must hit the rationals."""
+    x = np.array([[1.0, 0.0], [0.0, 3.0]])
+    c, mu = np.array([[1.0], [2.0]]), np.zeros(2)
+    want = (np.sqrt(161.0) / 12.0, np.array([[6.0 / 49.0], [108.0 / 49.0]]), np.array([-1.0 / 12.0, 1.0 / 3.0]))
+    for got in (oracle.iterate(x, 1.0, c, mu), _restate().iterate_with_prior(x, 1.0, c, mu)):
+        assert abs(got[0] - want[0]) < 1e-15
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-14)
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-14)
+    z, cov = oracle.infer(x, 1.0, c, mu)
+    np.testing.assert_allclose(z[:, 0], [1.0 / 6.0, 1.0], rtol=1e-14)
+    np.testing.assert_allclose(cov[:, 0, 0], [1.0 / 6.0, 1.0 / 6.0], rtol=1e-13)
+
+
+@pytest.mark.parametrize("which", ["none", "ridge", "noise", "mean", "all"])
+def test_second_restatement_agrees_on_the_em_step(oracle, which):
+    """oracle/ppca_oracle.c against oracle/restate_numpy.py (written independently from the Rust) on iterate_with_prior
+    with each prior hook (ppca_model.rs:307-308, :360-371, :379-384; prior.rs:97-110), weighted, with an all-masked
+    sample and an empty dimension: 1e-12."""
+    R = _restate()
+    x, w, s, c, mu, rng = _case(100 + len(which))
+    d = x.shape[1]
+    a = rng.standard_normal((d, d))
+    cov = a @ a.T / d + 0.5 * np.eye(d)
+    kw = {}
+    if which in ("ridge", "all"):
+        kw["transformation_precision"] = 0.7
+    if which in ("noise", "all"):
+        kw.update(isotropic_noise_alpha=3.0, isotropic_noise_beta=2.0)
+    if which in ("mean", "all"):
+        kw.update(mean=np.linspace(-1, 1, d), mean_covariance=cov)
+    po = oracle.Prior(**kw) if kw else None
+    pn = R.PriorN(**kw) if kw else None
+    np.testing.assert_allclose(oracle.llks(x, s, c, mu), R.llks(x, s, c, mu), rtol=1e-12, atol=1e-12)
+    for _ in range(2):
+        got = oracle.iterate(x, s, c, mu, w, po)
+        want = R.iterate_with_prior(x, s, c, mu, w, pn)
+        assert abs(got[0] - want[0]) < 1e-12 * want[0]
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-10, atol=1e-12)
+        if "transformation_precision" not in kw:
+            np.testing.assert_array_equal(got[1][5], c[5])  # empty dimension: singular system, old row kept (:313-321)
+        else:
+            np.testing.assert_array_equal(got[1][5], np.zeros(c.shape[1]))  # tau I is solvable: the row shrinks to 0
+        s, c, mu = got
+
+
+def test_second_restatement_agrees_on_the_mixture_step(oracle):
+    """mix.rs:281-337 in both restatements, weighted, three components."""
+    R = _restate()
+    x, w, _, _, _, rng = _case(7, n=90, d=8, k=2, mask=0.25)
+    nm = 3
+    sig, cs, ms = rng.uniform(0.6, 1.2, nm), rng.standard_normal((nm, 8, 2)), rng.standard_normal((nm, 8))
+    lw = np.log(rng.dirichlet(np.ones(nm)))
+    got = oracle.mix_iterate(x, sig, cs, ms, lw, w)
+    want = R.mix_iterate(x, sig, list(cs), list(ms), lw, w)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-11)
+    np.testing.assert_allclose(got[1], np.array(want[1]), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(got[2], np.array(want[2]), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(got[3], want[3], rtol=1e-11, atol=1e-12)

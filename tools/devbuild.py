@@ -15,5 +15,5 @@ if "--asm" in sys.argv:
 assert all(p.wait() == 0 for p in procs)
 capi = "/tmp/ppca_capi.dev.o" if "--timing" in sys.argv else os.path.join(C, "ppca_capi.o")
 out = os.path.join(ROOT, "ppca_rs_amd", "libppca_hip_dev.so")
-subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out, "/tmp/ppca_kernels.dev.o", os.path.join(C, "ppca_generic.o"), capi])
+subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out, "/tmp/ppca_kernels.dev.o", os.path.join(C, "ppca_generic.o"), os.path.join(C, "ppca_comm.o"), capi])
 print(out)
