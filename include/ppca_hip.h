@@ -255,6 +255,12 @@ int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, con
  * ppca_vector_sum_dev: sum_i v_i (w_i) (:324-325 and the llk total). */
 int ppca_mix_responsibilities_dev(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
                                   int32_t n_models, double *u_dev, double *lse_dev);
+/* One component of the sharded M-step in one call: weights exp(u_i - shift) (mix.rs:320-323; shift = the maximum over
+ * ALL shards), their sum over this shard (nullable), and the component's weighted statistics (ppca_stats_len doubles,
+ * device).  Rows whose weight is exactly zero add exactly nothing to any statistic and are skipped: the pass gathers
+ * the others (rows_used, nullable, reports how many).  Synchronises. */
+int ppca_mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, const double *u_dev, double shift,
+                             double *stats_dev, double *sum_host, int64_t *rows_used);
 int ppca_vector_max_dev(ppca_ctx *ctx, const double *v_dev, int64_t n, double *max_host);
 int ppca_vector_exp_shift_dev(ppca_ctx *ctx, const double *v_dev, double shift, int64_t n, double *out_dev);
 int ppca_vector_sum_dev(ppca_ctx *ctx, const double *v_dev, const double *w_dev, int64_t n, double *sum_host);

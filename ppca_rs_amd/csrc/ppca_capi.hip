@@ -463,28 +463,34 @@ static int check_pair(const ppca_dataset *ds, const ppca_model *model) {
     return check_path(model->d, model->k);
 }
 
-extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_dev) {
+// rows / wsel / nsel: gathered pass over nsel rows of the dataset (fused path only): sample i is row rows[i] with
+// weight wsel[i]; rows == nullptr: the whole dataset with its own weights.
+static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_dev, const int *rows,
+                              const double *wsel, int64_t nsel) {
     if (!ctx || !stats_dev) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
     USE_CTX(ctx);
     const StatsLayout L(model->d, model->k);
-    if (ds->n == 0) {
+    const int64_t n = rows ? nsel : ds->n;
+    if (n == 0) {
         HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * (size_t)L.len, ctx->stream));
         return PPCA_OK;
     }
     if (ppca_path_kind(model->d, model->k) == 0) {
+        if (rows) return fail(PPCA_ERR_INVALID, "gathered passes run on the fused path only");
         if (int rc = ensure(ctx->gws, ctx->gws_cap, generic_workspace_bytes(model->d, model->k, ds->n))) return rc;
         HIP_TRY(generic_em_accumulate(ds->X, ds->d, ds->w, ds->n, ds->d, model->k, model->p(), stats_dev, ctx->gws->p,
                                       ctx->n_cu, ctx->stream));
         return PPCA_OK;
     }
-    const int grid = fused_grid(ds->n, ctx->n_cu);
+    const int grid = fused_grid(n, ctx->n_cu);
     if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)grid * L.len)) return rc;
     PassArgs a{};
     a.X = ds->X;
     a.ldx = ds->d;
-    a.w = ds->w;
-    a.n = ds->n;
+    a.w = rows ? wsel : ds->w;
+    a.rows = rows;
+    a.n = n;
     a.d = ds->d;
     a.model = model->p();
     a.part = static_cast<double *>(ctx->part->p);
@@ -516,7 +522,7 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
         double t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int g = 0; g < grid; ++g)
             for (int i = 0; i < 16; ++i) t[i] += h[(size_t)g * 16 + i] / grid;
-        const double tiles = (double)((ds->n + FUSED_TILE - 1) / FUSED_TILE) / grid;
+        const double tiles = (double)((n + FUSED_TILE - 1) / FUSED_TILE) / grid;
         fprintf(stderr, "[ppca P2 cycles/tile] mask bytes %.0f  digit pairs {7,6},{5,4} %.0f  b loop %.0f  pairs {3,2},{1,0} + stores + barrier %.0f\n",
                 t[12] / tiles, t[13] / tiles, t[14] / tiles, t[1] / tiles);
         fprintf(stderr, "[ppca phase cycles/tile] P1 %.0f  P2 %.0f  P3 %.0f (wave 0: factor %.0f, solve %.0f, columns %.0f, scalars %.0f, barrier %.0f)  P4 %.0f (cross+barrier %.0f, mask+staging %.0f, barrier %.0f)  (tiles/WG %.1f)\n",
@@ -526,6 +532,10 @@ extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_mo
     }
 #endif
     return PPCA_OK;
+}
+
+extern "C" int ppca_em_accumulate(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_dev) {
+    return em_accumulate_impl(ctx, ds, model, stats_dev, nullptr, nullptr, 0);
 }
 
 // Dense solve A x = b (n x n, row-major) by LU with partial pivoting; false if singular.
@@ -849,11 +859,16 @@ static int mix_check(ppca_dataset *ds, ppca_model *const *models, int32_t nm) {
 static int mix_posteriors(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
                           int32_t nm, BufRef &llk, BufRef &u, BufRef &lse, BufRef *logpost) {
     const int64_t n = ds->n;
-    if (int rc = dev_alloc(sizeof(double) * (size_t)nm * n, &llk)) return rc;
-    if (int rc = dev_alloc(sizeof(double) * (size_t)nm * n, &u)) return rc;
-    if (int rc = dev_alloc(sizeof(double) * (size_t)n, &lse)) return rc;
-    if (logpost)
-        if (int rc = dev_alloc(sizeof(double) * (size_t)nm * n, logpost)) return rc;
+    if (int rc = ensure(ctx->mix[0], ctx->mix_cap[0], sizeof(double) * (size_t)nm * n)) return rc;
+    if (int rc = ensure(ctx->mix[1], ctx->mix_cap[1], sizeof(double) * (size_t)nm * n)) return rc;
+    if (int rc = ensure(ctx->mix[2], ctx->mix_cap[2], sizeof(double) * (size_t)n)) return rc;
+    llk = ctx->mix[0];
+    u = ctx->mix[1];
+    lse = ctx->mix[2];
+    if (logpost) {
+        if (int rc = ensure(ctx->mix[3], ctx->mix_cap[3], sizeof(double) * (size_t)nm * n)) return rc;
+        *logpost = ctx->mix[3];
+    }
     for (int c = 0; c < nm; ++c)
         if (int rc = ppca_llks_dev(ctx, ds, models[c], static_cast<double *>(llk->p) + (size_t)c * n)) return rc;
     // normalised log-weights (PPCAMix::new mix.rs:66-70)
@@ -900,6 +915,75 @@ extern "C" int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *
     return PPCA_OK;
 }
 
+// One component of the mixture M-step on this context's rows: sample weights exp(u_i - shift) (mix.rs:320-323), their
+// sum (:324-325), and the component's weighted statistics.  Rows whose weight is exactly zero contribute exactly
+// nothing to any statistic (all are linear in the weights): on the fused path they are dropped from the pass
+// (select_* kernels), which then gathers the remaining rows -- at d = 256 the exponential underflows for most samples
+// of the other clusters, so the K component passes together cost about as much as one.
+static int mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, const double *u_dev,
+                               const double *shift_dev, double *stats_dev, double *sum_host, int64_t *rows_used) {
+    USE_CTX(ctx);
+    const int64_t n = ds->n;
+    double *work = static_cast<double *>(ctx->work->p);
+    const StatsLayout L(model->d, model->k);
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * (size_t)L.len, ctx->stream));
+        if (sum_host) *sum_host = 0.0;
+        if (rows_used) *rows_used = 0;
+        return PPCA_OK;
+    }
+    if (int rc = ensure(ctx->mix[4], ctx->mix_cap[4], sizeof(double) * (size_t)n)) return rc;
+    double *w = static_cast<double *>(ctx->mix[4]->p);
+    const bool fused = ppca_path_kind(model->d, model->k) == 1 && n < (int64_t)1 << 31;
+    struct SkipLlk {  // the component passes' own llk is never read (the mixture llk comes from the llk sweep)
+        ppca_ctx *c;
+        explicit SkipLlk(ppca_ctx *ctx_) : c(ctx_) { c->skip_llk = 1; }
+        ~SkipLlk() { c->skip_llk = 0; }
+    } skip(ctx);
+    int rc = PPCA_OK;
+    if (fused) {
+        const int nb = select_blocks(n);
+        if (int e = ensure(ctx->mix[5], ctx->mix_cap[5], sizeof(int) * (size_t)n)) return e;
+        if (int e = ensure(ctx->mix[6], ctx->mix_cap[6], sizeof(int) * ((size_t)nb + 1))) return e;
+        BufRef rows = ctx->mix[5], counts = ctx->mix[6];
+        HIP_TRY(launch_select_positive(u_dev, shift_dev, n, static_cast<int *>(counts->p), static_cast<int *>(rows->p), w,
+                                       ctx->stream));
+        int m = 0;
+        HIP_TRY(hipMemcpyAsync(&m, static_cast<int *>(counts->p) + nb, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (rows_used) *rows_used = m;
+        HIP_TRY(launch_reduce_sum(w, nullptr, m, work + 1026, work, ctx->stream));
+        rc = em_accumulate_impl(ctx, ds, model, stats_dev, static_cast<int *>(rows->p), w, m);
+        if (rc == PPCA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PPCA_ERR_HIP, "synchronize failed");
+    } else {
+        HIP_TRY(launch_exp_shift(u_dev, shift_dev, n, w, ctx->stream));
+        HIP_TRY(launch_reduce_sum(w, nullptr, n, work + 1026, work, ctx->stream));
+        if (rows_used) *rows_used = n;
+        ppca_dataset *wds = nullptr;
+        rc = ppca_dataset_with_weights(ds, nullptr, w, &wds);
+        if (rc == PPCA_OK) rc = ppca_em_accumulate(ctx, wds, model, stats_dev);
+        if (rc == PPCA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PPCA_ERR_HIP, "synchronize failed");
+        ppca_dataset_free(wds);
+    }
+    if (rc) return rc;
+    if (sum_host) {
+        HIP_TRY(hipMemcpyAsync(sum_host, work + 1026, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return PPCA_OK;
+}
+
+extern "C" int ppca_mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, const double *u_dev,
+                                        double shift, double *stats_dev, double *sum_host, int64_t *rows_used) {
+    if (!ctx || !u_dev || !stats_dev) return fail(PPCA_ERR_INVALID, "null argument");
+    if (int rc = check_pair(ds, model)) return rc;
+    USE_CTX(ctx);
+    double *work = static_cast<double *>(ctx->work->p);
+    HIP_TRY(hipMemcpyAsync(work + 1025, &shift, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return mix_component_stats(ctx, ds, model, u_dev, work + 1025, stats_dev, sum_host, rows_used);
+}
+
 extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models_in,
                                 const double *log_weights_in, int32_t n_models, const ppca_prior *prior,
                                 ppca_model *const *models_out, double *log_weights_out, double *llk_in) {
@@ -918,27 +1002,21 @@ extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *con
         HIP_TRY(hipMemcpyAsync(llk_in, work + 1024, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    BufRef wc;
-    if (int rc = dev_alloc(sizeof(double) * (size_t)n, &wc)) return rc;
     std::vector<double> logsum(nm);
     for (int c = 0; c < nm; ++c) {
         const double *uc = static_cast<double *>(u->p) + (size_t)c * n;
-        // max (mix.rs:312-317), unnormalised posteriors (:320-323), log-sum (:324-325)
+        const StatsLayout L(models_in[c]->d, models_in[c]->k);
+        if (int rc = ensure(ctx->stats, ctx->stats_cap, sizeof(double) * (size_t)L.len)) return rc;
+        double *stats = static_cast<double *>(ctx->stats->p);
+        ctx->stats_llk_at = -1;
+        // max (mix.rs:312-317), un-normalised posteriors as weights (:320-323), log-sum (:324-325), weighted step (:326-328)
         HIP_TRY(launch_reduce_max(uc, n, work + 1025, work, ctx->stream));
-        HIP_TRY(launch_exp_shift(uc, work + 1025, n, static_cast<double *>(wc->p), ctx->stream));
-        HIP_TRY(launch_reduce_sum(static_cast<double *>(wc->p), nullptr, n, work + 1026, work, ctx->stream));
-        double h[2];
-        HIP_TRY(hipMemcpyAsync(h, work + 1025, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        logsum[c] = std::log(h[1]) + h[0];
-        ppca_dataset *wds = nullptr;
-        if (int rc = ppca_dataset_with_weights(ds, nullptr, static_cast<double *>(wc->p), &wds)) return rc;
-        ctx->skip_llk = 1;  // the component steps' own llk is never read (the mixture llk came from the llks above)
-        int rc = ppca_em_step(ctx, wds, models_in[c], prior, models_out[c], nullptr);  // :326-328
-        ctx->skip_llk = 0;
-        if (rc == PPCA_OK) rc = ppca_ctx_synchronize(ctx);
-        ppca_dataset_free(wds);
-        if (rc) return rc;
+        double mx = 0.0, sum = 0.0;
+        HIP_TRY(hipMemcpyAsync(&mx, work + 1025, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (int rc = mix_component_stats(ctx, ds, models_in[c], uc, work + 1025, stats, &sum, nullptr)) return rc;
+        logsum[c] = std::log(sum) + mx;
+        if (int rc = ppca_em_finalize(ctx, models_in[c], stats, prior, models_out[c])) return rc;
+        if (int rc = ppca_ctx_synchronize(ctx)) return rc;
     }
     // :335 robust_log_softmax
     double mx = logsum[0];

@@ -1,0 +1,113 @@
+// ppca_device.hpp -- device-side helpers shared by the fused-pass kernels (ppca_kernels.hip, ppca_em_roles.hip):
+// the LDS layout constants of a 32-sample tile, wave reductions on the DPP path, lane-targeted writes, compile-time
+// loops, the fp64 MFMA wrapper and the constants of the int8-sliced Gram table.  Not installed.
+#pragma once
+
+#include <type_traits>
+#include <utility>
+
+#include "ppca_internal.hpp"
+
+namespace ppca {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+template <int K>
+struct Cfg {
+    static constexpr int KP = K * (K + 1) / 2;
+    static constexpr int NTP = (KP + 15) / 16;  // column tiles holding vech(P)
+    static constexpr int NTM = NTP + 1;         // + the [w z | w] tile
+    static constexpr int B = FUSED_TILE;
+    static constexpr int DP = FUSED_MAX_D;
+    static constexpr int XS = DP + 2;           // x~ tile row stride (doubles): conflict-free A-operand reads
+    static constexpr int CS = K + 1;            // C tile row stride; column K is all zeros
+    static constexpr int GS = 16 * NTM + 1;     // [G | b] exchange row stride
+    static constexpr int WS = 16 * NTM + 2;     // [wP | wz | w] row stride
+    static constexpr int OFF_X = 0;
+    static constexpr int OFF_C = OFF_X + B * XS;
+    static constexpr int OFF_G = OFF_C + DP * CS;
+    static constexpr int OFF_W = OFF_G + 2 * B * GS;
+    static constexpr int OFF_M = OFF_W + B * WS;  // mask words, B x 4 u64
+    static constexpr int OFF_S = OFF_M + 2 * B * 4;  // (two parities: the next tile is staged behind P4)
+                                                     // then xx[B] doubles, m[B] ints
+    // running per-solver-lane scalars (kept out of registers: at this pressure hipcc parks loop-carried
+    // once-per-tile values in scratch and reloads them with an exposed vmcnt(0)):
+    // sq[NW <= 8 waves][B] | dev[B] | llk[B] | sumw[B] | nonempty[B] | det mantissa[B] | det exponent[B]
+    static constexpr int OFF_L = OFF_S + 2 * B;
+    static constexpr int LDS_DOUBLES = OFF_L + 22 * B;  // (sq has two slots per solver sample when the waves pair lanes)
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Wave-wide sum on the DPP data path (VALU speed, no LDS crossbar): quad swaps, half-row and row mirrors,
+// then row_bcast15 / row_bcast31 carry the row totals forward; lane 63 ends up with the total, which is
+// returned as a wave-uniform value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_f64<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 = total
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// dst[LANE] = sval (wave-uniform value into ONE lane of a VGPR): no compare mask, no select.  The lane
+// select is an immediate: the instruction admits a single SGPR operand (constant-bus limit).
+template <int LANE>
+__device__ __forceinline__ int writelane(int dst, int sval) {
+    // s_nop 1: gfx940+ needs 2 wait states between a VALU that writes an SGPR (the v_cmp ballot) and a
+    // VALU that reads it; hipcc pads its own code but nothing inside an asm statement.
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
+    return dst;
+}
+// As writelane, for a value produced by the SCALAR unit (no VALU-writes-SGPR hazard to pad).
+template <int LANE>
+__device__ __forceinline__ int writelane_s(int dst, int sval) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
+    return dst;
+}
+// mask bit of the lane ? v : 0.0 with the wave mask taken straight from its SGPR pair (a C++ select on
+// (mask >> lane) & 1 would rebuild the predicate with vector shifts).
+__device__ __forceinline__ double keep_if(double v, unsigned long long mask) {
+    const long long b = __double_as_longlong(v);
+    int lo, hi;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(lo) : "v"((int)b), "s"(mask));
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(hi) : "v"((int)(b >> 32)), "s"(mask));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ int8-sliced Gram operand (see ppca_kernels.hip)
+constexpr int QS = 8;
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
+template <int K>
+constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
+
+
+}  // namespace ppca

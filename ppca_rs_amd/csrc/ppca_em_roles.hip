@@ -1,0 +1,646 @@
+// ppca_em_roles.hip -- the EM pass (E-step + every M-step reduction in ONE sweep over X) as an 8-wave workgroup
+// with two ROLES, two waves per SIMD:
+//
+//   front waves 0-3      stage the rows of tile t (P1), [G | b] of the tile (P2: int8-sliced Gram + fp64 b),
+//                        the per-sample k x k solve (P3) and the x~-side statistics cross / sumx (P4a)
+//   accumulator waves 4-7  S / U / totals (256 x 66) += Mask^T [wP | wz | w] of tile t-1 (P4b): 160 of the 224
+//                        fp64 MFMAs of a tile, with the 168 accumulator registers that go with them
+//
+// Why: v_mfma_f64 and every other vector instruction share one issue port per SIMD (tools/ubench_shadow.hip: a wave
+// streaming fp64 MFMAs starves a second wave's VALU completely, and vice versa nothing of one wave overlaps its own
+// MFMA), so a SIMD's time is the SUM of its MFMA cycles and its VALU issue cycles -- plus every cycle in which its
+// only wave waits (LDS operands, v_rsq chains of the Cholesky, memory, barriers): ~8 k of the 27.8 k cycles per
+// tile of the single-role kernel (pass_kernel<K, true, 4, true>).  With two waves of DIFFERENT phases on each SIMD
+// the port stays busy while one of them waits.  The split is by register budget: two waves per SIMD have 256
+// registers each; the accumulator role fits because it does nothing else, the front role because it holds no
+// mask-side accumulators.
+//
+// MEASURED (round 2, N = 10 M, d = 256, k = 10): 71.2 EM it/s against 71.8 for pass_kernel -- no gain, so this
+// kernel is OPT-IN (PPCA_EM_ROLES=1), kept as the record of the experiment and as a second implementation the
+// parity tests can run.  Reading: an fp64 MFMA occupies the port for 64 cycles and cannot be pre-empted, while the
+// front role is a chain of dependent fp64 operations 8-16 cycles apart; every time the front wave waits for a
+// result the accumulator wave slips in an MFMA and the dependent operation then waits ~64 cycles instead of ~10.
+// The accumulator role races through its 9 k cycles, the front role crawls meanwhile and afterwards runs alone at
+// its stand-alone pace -- the phases serialise after all.  Thread-level parallelism cannot fill gaps that are
+// shorter than one MFMA; only an in-wave interleave (dependent VALU chains placed BETWEEN a wave's own MFMAs, as
+// pass_kernel already does for the staging) hides them.
+//
+// Hand-off: [wP | wz | w] rows and mask words are double-buffered in LDS; ONE workgroup barrier per tile (front has
+// finished P3(t), the accumulators P4b(t-1)); the front waves synchronise among themselves three more times per
+// tile on an LDS counter.  Per-sample arithmetic, tile order and the order of every floating-point sum are those of
+// pass_kernel, so the statistics are bit-identical to it.
+//
+// What it replaces in the reference: infer (ppca/src/ppca_model.rs:221-227), the cross moment (:281-293), the d
+// second-moment scans (:294-306), the noise 4-tuple (:328-358) and llk (:142-149), as pass_kernel does.
+#include <atomic>
+#include <cstdlib>
+
+#include "ppca_device.hpp"
+
+namespace ppca {
+
+template <int K>
+struct CfgR {
+    using c = Cfg<K>;
+    static constexpr int KP = c::KP, NTP = c::NTP, NTM = c::NTM, B = c::B, DP = c::DP, XS = c::XS, CS = c::CS;
+    static constexpr int GS = 16 * NTM + 1;  // [G (16 NTP) | b partial of dims 0-127 (16)] row stride
+    static constexpr int BS = 17;            // b partial of dims 128-255
+    static constexpr int WS = 16 * NTM + 2;  // [wP | wz | w] row stride
+    static constexpr int OFF_X = 0;
+    static constexpr int OFF_C = OFF_X + B * XS;
+    static constexpr int OFF_G = OFF_C + DP * CS;
+    static constexpr int OFF_B1 = OFF_G + B * GS;
+    static constexpr int OFF_W = OFF_B1 + B * BS;       // two buffers (tile parity)
+    static constexpr int OFF_M = OFF_W + 2 * B * WS;    // mask words, two parities x B x 4 u64
+    static constexpr int OFF_S = OFF_M + 2 * B * 4;     // cross-wave scratch [B] | popcounts [B ints]
+    static constexpr int OFF_L = OFF_S + 2 * B;         // running scalars: sq[4 waves][2 B] | dev | llk | w | ne | pm | px
+    static constexpr int OFF_BAR = OFF_L + 14 * B;      // front-wave barrier counter
+    static constexpr int LDS_DOUBLES = OFF_BAR + 2;
+};
+
+// Barrier among the four front waves on a monotonic LDS counter (the accumulator waves do not take part).  A wave's
+// LDS operations execute in order, so its add follows its stores; the others read only after seeing the count.
+__device__ __forceinline__ void front_barrier(unsigned *ctr, unsigned &target, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    target += 4;
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+        const unsigned seen = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(seen - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void em_roles_kernel(PassArgs p) {
+    using cfg = CfgR<K>;
+    constexpr int KP = cfg::KP, NTP = cfg::NTP, NTM = cfg::NTM, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS,
+                  BS = cfg::BS, WS = cfg::WS;
+    constexpr int NF = 4;              // waves per role
+    constexpr int RPW = B / NF;        // rows staged per front wave
+    constexpr int DPS = cfg::DP / 2;   // dims per K-split of b = X~ C
+    constexpr int STEPS = DPS / 4;
+    constexpr int RT = 16 / NF;        // 16-dim row tiles per wave in P4
+    constexpr int DW = cfg::DP / NF;   // dims owned by a wave in P4
+    constexpr int PADS = 16 * NTP - KP;
+    constexpr int SMALL_COLS = K + 1 - PADS;
+    constexpr bool SPLIT = SMALL_COLS > 0 && SMALL_COLS <= 4 && PADS > 0;  // see pass_kernel
+    constexpr int NTMB = SPLIT ? NTP : NTM;
+    static_assert(NTP <= NF, "int8 Gram: one front wave per packed-column tile");
+    static_assert(QS == 8, "digit grouping assumes 8 slices");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Xs = sm + cfg::OFF_X;
+    double *Cs = sm + cfg::OFF_C;
+    double *Gs = sm + cfg::OFF_G;
+    double *B1 = sm + cfg::OFF_B1;
+    double *Ws = sm + cfg::OFF_W;
+    unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
+    double *xxs = sm + cfg::OFF_S;
+    int *mcnt = reinterpret_cast<int *>(sm + cfg::OFF_S + B);
+    double *scl = sm + cfg::OFF_L;
+    unsigned *bar = reinterpret_cast<unsigned *>(sm + cfg::OFF_BAR);
+
+    if (p.qflag) {  // qprep's dynamic-range guard: the fp64-Gram pass_kernel runs instead
+        int unsafe = 0;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) unsafe |= p.qflag[t];
+        if (unsafe) return;
+    }
+    const int tid = threadIdx.x, lane_entry = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool front = wave8 < NF;
+    const int wave = wave8 & (NF - 1);  // index within the role
+    const int d = p.d;
+    const int64_t n = p.n;
+    const double *mC = p.model + MODEL_HDR;
+    const double *mMean = mC + (int64_t)d * K;
+    const double s2 = p.model[1], lnsig = p.model[2];
+
+    for (int idx = tid; idx < cfg::DP * CS; idx += 512) {
+        int j = idx / CS, a = idx - j * CS;
+        Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
+    }
+    for (int idx = tid; idx < 2 * B * WS; idx += 512) Ws[idx] = 0.0;
+    constexpr int SQW = 2 * B;  // sq slots per front wave (lane pairs, see P3)
+    constexpr int L_DEV = NF * SQW, L_LLK = L_DEV + B, L_W = L_DEV + 2 * B, L_NE = L_DEV + 3 * B, L_PM = L_DEV + 4 * B,
+                  L_PX = L_DEV + 5 * B;
+    for (int idx = tid; idx < L_DEV + 6 * B; idx += 512) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
+    if (tid == 0) *bar = 0u;
+
+    const int64_t ntiles = (n + B - 1) / B;
+    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+    __syncthreads();
+
+    if (!front) {
+        // =========================================================== accumulator role: P4b of every tile
+        d4_t accM[RT][NTM];
+        double accS[RT];  // SPLIT: the 4-column group, D lane = 16 i + 4 block + j
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+#pragma unroll
+            for (int t = 0; t < NTM; ++t) accM[r][t] = d4_t{0, 0, 0, 0};
+            accS[r] = 0.0;
+        }
+        for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
+            int lane = lane_entry;
+            asm volatile("" : "+v"(lane));  // (per-tile address arithmetic instead of hoisted, parked registers)
+            const int l15 = lane & 15, l4 = lane >> 4;
+            const int par = (int)((tile - tile_begin) & 1);
+            const unsigned long long *Msc = Ms + par * 4 * B;
+            const double *Wsc = Ws + par * B * WS;
+            __syncthreads();  // front: P3(tile) done -> W rows and mask words of this parity are final
+            unsigned long long mwc = Msc[l4 * 4 + (DW * wave) / 64];
+            double bwc[NTMB], bsc = 0.0;
+#pragma unroll
+            for (int t = 0; t < NTMB; ++t) bwc[t] = Wsc[l4 * WS + 16 * t + l15];
+            if constexpr (SPLIT) bsc = Wsc[l4 * WS + 16 * NTP + PADS + (lane & 3)];
+            static_for<8>([&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                unsigned long long mwn = 0ull;
+                double bwn[NTMB], bsn = 0.0;
+                constexpr int PER_R = NTMB + (SPLIT ? 1 : 0);
+                constexpr int SLOTS = RT * PER_R;
+                static_for<SLOTS>([&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value, r = i / PER_R, t = i % PER_R;
+                    const int sh = ((DW * wave) & 63) + 16 * r;
+                    const int am_hi = __builtin_amdgcn_sbfe((int)(unsigned)(mwc >> (sh & 32)), (sh & 31) + l15, 1) & 0x3FF00000;
+                    const double am = __hiloint2double(am_hi, 0);
+                    if constexpr (t < NTMB) {
+                        accM[r][t] = mfma(am, bwc[t], accM[r][t]);
+                    } else {
+                        accS[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, bsc, accS[r], 0, 0, 0);
+                    }
+                    if constexpr (i == SLOTS / 4 && s + 1 < 8) {  // next step's operands, well ahead of their use
+                        const int smp = 4 * (s + 1) + l4;
+                        mwn = Msc[smp * 4 + (DW * wave) / 64];
+#pragma unroll
+                        for (int tt = 0; tt < NTMB; ++tt) bwn[tt] = Wsc[smp * WS + 16 * tt + l15];
+                        if constexpr (SPLIT) bsn = Wsc[smp * WS + 16 * NTP + PADS + (lane & 3)];
+                    }
+                });
+                if constexpr (s + 1 < 8) {
+                    mwc = mwn;
+#pragma unroll
+                    for (int t = 0; t < NTMB; ++t) bwc[t] = bwn[t];
+                    bsc = bsn;
+                }
+            });
+        }
+        // per-workgroup partial: S, U, totals
+        {
+            const int lane = lane_entry, l15 = lane & 15, l4 = lane >> 4;
+            StatsLayout L(d, K);
+            double *out = p.part + (int64_t)blockIdx.x * L.len;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int dim = DW * wave + 16 * r + l4 + 4 * q;  // C/D row of v_mfma_f64_16x16x4
+                    if (dim >= d) continue;
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t) {
+                        const int c = 16 * t + l15;
+                        if (c < KP) out[L.S + (int64_t)dim * KP + c] = accM[r][t][q];
+                        if constexpr (SPLIT) {
+                            if (t == NTP - 1 && c >= KP) {
+                                const int a = c - KP;
+                                if (a < K) out[L.U + (int64_t)dim * K + a] = accM[r][t][q];
+                                else if (a == K) out[L.totals + dim] = accM[r][t][q];
+                            }
+                        }
+                    }
+                    if constexpr (!SPLIT) {
+                        if (l15 < K) out[L.U + (int64_t)dim * K + l15] = accM[r][NTP][q];
+                        else if (l15 == K) out[L.totals + dim] = accM[r][NTP][q];
+                    }
+                }
+                if constexpr (SPLIT) {  // 4x4x4 group: D lane = 16 i + 4 block + j
+                    const int dim = DW * wave + 16 * r + 4 * ((lane >> 2) & 3) + (lane >> 4);
+                    const int a = PADS + (lane & 3);
+                    if (dim < d) {
+                        if (a < K) out[L.U + (int64_t)dim * K + a] = accS[r];
+                        else if (a == K) out[L.totals + dim] = accS[r];
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // =============================================================== front role
+    unsigned bar_target = 0u;
+    double mu[4];  // staging lane map: lane l holds dims 128 h + 2 l + e (element q = 2 h + e) of a row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int j = 128 * (q >> 1) + 2 * lane_entry + (q & 1);
+        mu[q] = (j < d) ? mMean[j] : 0.0;
+    }
+    d4_t accX[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) accX[r] = d4_t{0, 0, 0, 0};
+    const double inv_s2 = 1.0 / s2;
+    double xr[RPW][4];
+    bool dim_ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dim_ok[q] = 128 * (q >> 1) + 2 * lane_entry + (q & 1) < d;
+    unsigned long long dimmask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dimmask[q] = __builtin_amdgcn_ballot_w64(dim_ok[q]);
+    const int64_t nleft = n - tile_begin * B;
+    const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));
+    const double *Xwg = p.X + tile_begin * B * p.ldx;
+    // rows arrive through a per-row buffer descriptor (scalar address, dims past d read as zero), clamped to real rows
+    auto load_row = [&](int64_t tile, int r) {
+        const int rel = (int)(tile - tile_begin) * B + wave * RPW + r;
+        const int rc = rel < nrel ? rel : nrel - 1;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(Xwg + (int64_t)rc * p.ldx), 0, d * (int)sizeof(double), 0x00020000);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, 0);
+            xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+            xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
+    const bool gram_wave = NTP >= NF || wave < NTP;
+    i4_t qbA[2][4];
+    auto load_pair = [&](i4_t(&dst)[2][4], int sl0) {
+        int qbase = wave * QS * 4 * 1024;
+        asm volatile("" : "+s"(qbase));
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16, qbase + ((sl0 + u) * 4 + kc) * 1024, 0);
+                dst[u][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+            }
+    };
+    // ---- P1: one tile = RPW rows per wave; mask words / popcounts gathered into the lane that stores them
+    int st_wlo = 0, st_whi = 0, st_m = 0;
+    double xx_run = 0.0;  // sum_i w_i |x~_i|^2 of this wave's rows (sigma^2 and the llk are linear in it)
+    auto stage_row = [&](int64_t t, int lane, auto r_tag) {
+        constexpr int r = decltype(r_tag)::value;
+        const int ri = wave * RPW + r;
+        const bool row_ok = t < tile_end && (int)(t - tile_begin) * B + ri < nrel;  // wave-uniform
+        double xt[4];
+        unsigned long long bal[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double v = xr[r][q];
+            // observed <=> finite (dataset.rs:19-22): |v| < inf straight into an SGPR pair, validity ANDed on the scalar unit
+            bal[q] = __builtin_amdgcn_fcmp(__builtin_fabs(v), __builtin_inf(), 4) & (row_ok ? dimmask[q] : 0ull);
+            xt[q] = keep_if(v - mu[q], bal[q]);  // select, never multiply (utils.rs:118-127)
+        }
+        double pc_xx = 0.0;
+        int pc_m = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            auto weave = [&](unsigned ev, unsigned od) {
+                unsigned long long re, ro;
+                asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(re) : "s"(ev));
+                asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(ro) : "s"(od));
+                return (re & 0x5555555555555555ull) | (ro & 0xAAAAAAAAAAAAAAAAull);
+            };
+            const unsigned long long b0 = bal[2 * h], b1 = bal[2 * h + 1];
+            const unsigned long long w0 = weave((unsigned)b0, (unsigned)b1);
+            const unsigned long long w1 = weave((unsigned)(b0 >> 32), (unsigned)(b1 >> 32));
+            if (h == 0) {
+                st_wlo = writelane_s<4 * r>(st_wlo, (int)(unsigned)w0);
+                st_whi = writelane_s<4 * r>(st_whi, (int)(unsigned)(w0 >> 32));
+                st_wlo = writelane_s<4 * r + 1>(st_wlo, (int)(unsigned)w1);
+                st_whi = writelane_s<4 * r + 1>(st_whi, (int)(unsigned)(w1 >> 32));
+            } else {
+                st_wlo = writelane_s<4 * r + 2>(st_wlo, (int)(unsigned)w0);
+                st_whi = writelane_s<4 * r + 2>(st_whi, (int)(unsigned)(w0 >> 32));
+                st_wlo = writelane_s<4 * r + 3>(st_wlo, (int)(unsigned)w1);
+                st_whi = writelane_s<4 * r + 3>(st_whi, (int)(unsigned)(w1 >> 32));
+            }
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 * h + 2 * lane) = d2_t{xt[2 * h], xt[2 * h + 1]};
+            pc_xx += xt[2 * h] * xt[2 * h];
+            pc_xx += xt[2 * h + 1] * xt[2 * h + 1];
+            pc_m += __popcll(b0) + __popcll(b1);
+        }
+        st_m = writelane<r>(st_m, pc_m);
+        const int64_t row = t * B + ri;
+        const double wr = p.w ? p.w[row < n ? row : n - 1] : 1.0;  // wave-uniform (scalar load)
+        xx_run += wr * pc_xx;
+    };
+    auto stage_tile = [&](int64_t t, int lane, int par) {
+        st_wlo = st_whi = st_m = 0;
+        static_for<RPW>([&](auto r_tag) { stage_row(t, lane, r_tag); });
+        const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
+        if (lane < 4 * RPW) Ms[par * 4 * B + wave * 4 * RPW + lane] = myw;
+        if (lane < RPW) mcnt[wave * RPW + lane] = st_m;
+    };
+
+    if (tile_begin < tile_end) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) load_row(tile_begin, r);
+        load_pair(qbA, 6);
+        stage_tile(tile_begin, lane_entry, 0);
+    }
+    front_barrier(bar, bar_target, lane_entry);
+
+    for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
+        int lane = lane_entry;
+        asm volatile("" : "+v"(lane));
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int colb = (l15 < K) ? l15 : K;
+        const int par = (int)((tile - tile_begin) & 1);
+        const unsigned long long *Msc = Ms + par * 4 * B;
+        double *Wsc = Ws + par * B * WS;
+        // ------------------------------------------------------------ P2: [G | b] of the tile
+        {
+            const int rt = wave & 1, kq = wave >> 1;
+            const int si = 16 * rt + l15;
+            d4_t accb = d4_t{0, 0, 0, 0};
+            const double *xrow = Xs + si * XS + DPS * kq + l4;
+            const double *cpc = Cs + (DPS * kq + l4) * CS + colb;
+            i4_t af[2][4];
+            double v[2][4];
+            // one digit pair: contract, then fold the exact integer digit sums (|sum| <= 2^14) into the running fp64
+            // value, Horner in 128^2
+            auto group = [&](const i4_t(*qb)[4], bool first) {
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2) {
+                    i4_t ia[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        ia[u] = i4_t{0, 0, 0, 0};
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc)
+                            ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt2][kc], qb[u][kc], ia[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int part = ia[1][r] * 128 + ia[0][r];
+                        v[rt2][r] = first ? (double)part : v[rt2][r] * 16384.0 + (double)part;
+                    }
+                }
+            };
+            double qs = 0.0;
+            i4_t qbB[2][4];
+            {
+                unsigned long long mwd[2][4];
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) mwd[rt2][kc] = Msc[(16 * rt2 + l15) * 4 + kc];
+                __builtin_amdgcn_sched_barrier(0);
+                load_pair(qbB, 4);
+                if (gram_wave) qs = p.qscale[16 * wave + l15];
+                __builtin_amdgcn_sched_barrier(0);
+                // A = mask bytes: lane (sample 16 rt2 + l15, dims 64 kc + 16 l4 .. +15); 4 bits -> 4 bytes by one
+                // multiply: (x * 0x204081) & 0x01010101 puts bit i of x into byte i
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) {
+                        const unsigned bits = (unsigned)(mwd[rt2][kc] >> (16 * l4)) & 0xFFFFu;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
+                    }
+                group(qbA, true);   // digits {7,6}: requested during the previous tile's P4a
+                load_pair(qbA, 2);
+                group(qbB, false);  // digits {5,4}
+                load_pair(qbB, 0);
+            }
+            {
+                // b = X~ C: operands of the next four k-steps are requested before the current four MFMAs issue
+                constexpr int CH = 4;
+                double axb[2][CH], cbb[2][CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    axb[0][u] = xrow[4 * u];
+                    cbb[0][u] = cpc[4 * u * CS];
+                }
+#pragma unroll
+                for (int c = 0; c < STEPS / CH; ++c) {
+                    if (c + 1 < STEPS / CH) {
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
+                            cbb[(c + 1) & 1][u] = cpc[4 * ((c + 1) * CH + u) * CS];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) accb = mfma(axb[c & 1][u], cbb[c & 1][u], accb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            group(qbA, false);  // digits {3,2}
+            group(qbB, false);  // digits {1,0}
+            if (gram_wave) {
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)  // C/D map of the 16x16 integer MFMA: row = 4 (lane >> 4) + reg
+                        Gs[(16 * rt2 + 4 * l4 + r) * GS + 16 * wave + l15] = v[rt2][r] * qs;
+            }
+            // the two K-split partials of b are summed by the solver in a fixed order (p0 + p1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kq == 0) Gs[(16 * rt + l4 + 4 * r) * GS + 16 * NTP + l15] = accb[r];
+                else B1[(16 * rt + l4 + 4 * r) * BS + l15] = accb[r];
+            }
+        }
+        front_barrier(bar, bar_target, lane_entry);
+        // ------------------------------------------------------------ P3: per-sample k x k solve
+        // Every front wave factors every sample (lane = sample, lanes 32-63 mirror 0-31) and the waves share the
+        // independent columns of M^-1, two per instruction stream (lane i: column 2p, lane i + 32: column 2p + 1);
+        // wave 0 also owns z, llk and the scalars.
+        {
+            const int i = lane & (B - 1);
+            const int hi = lane >> 5;
+            const int64_t row = tile * B + i;
+            const double *g0 = Gs + i * GS;
+            const double *b1 = B1 + i * BS;
+            const double wgt = (row < n) ? (p.w ? p.w[row] : 1.0) : 0.0;
+            const int m = mcnt[i];
+            double *wrow = Wsc + i * WS;
+            double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;
+            const double sq_run = scl[wave * SQW + lane];
+            Posterior<K> post;
+            double pm;
+            int pe;
+            post.factor([&](int e) { return g0[e]; }, s2, pm, pe);
+            double z[K], quad, zz;
+            post.solve([&](int a) { return g0[16 * NTP + a] + b1[a]; }, z, quad, zz);
+            double trpart = 0.0;
+            if constexpr (K >= 2) {
+#pragma unroll
+                for (int pp = 0; pp < (K + 1) / 2; ++pp) {
+                    if (pair_owner(K, pp, NF) != wave) continue;
+                    const int c0 = 2 * pp;
+                    const double zc = (hi && c0 + 1 < K) ? z[c0 + 1 < K ? c0 + 1 : c0] : z[c0];
+                    // P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439), weighted
+                    trpart += post.minv_column_pair(c0, hi, [&](int t, double v, bool ok) {
+                        if (ok && c0 + hi < K) wrow[tri(t, c0) + hi] = wgt * (z[t] * zc + s2 * v);
+                    });
+                }
+            } else {
+                if (wave == column_owner(K, 0, NF) && hi == 0)
+                    trpart += post.minv_column(0, [&](int a, int cc, double v) { wrow[tri(a, cc)] = wgt * (z[a] * z[cc] + s2 * v); });
+            }
+            // tr(C_o Sigma C_o^T) = <Sigma, G> = s2 (K - s2 tr M^-1)  (:345); all-masked samples are filtered out (:333)
+            if (m > 0) sc_sq -= wgt * s2 * s2 * trpart;
+            if (wave == 0 && hi == 0) {
+                const double run_dev = scl[L_DEV + i], run_llk = scl[L_LLK + i], run_w = scl[L_W + i], run_ne = scl[L_NE + i];
+                const double run_pm = scl[L_PM + i], run_px = scl[L_PX + i];
+                double *zrow = wrow + 16 * NTP;  // W row = [w P (K') | 0.. | w z (K) | w | 0..]
+#pragma unroll
+                for (int a = 0; a < K; ++a) zrow[a] = wgt * z[a];
+                zrow[K] = wgt;
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int a = 0; a < PADS; ++a) wrow[KP + a] = (a < K) ? wgt * z[a] : wgt;
+                }
+                if (m > 0) {
+                    sc_sq += wgt * s2 * (double)K;
+                    sc_dev += wgt * (0.0 - quad - s2 * zz);  // |x~ - C_o z|^2 minus |x~|^2, added in the epilogue (:346)
+                    sc_ne += (row < n) ? 1.0 : 0.0;
+                }
+                const double lk0 = sample_llk_nolog(0.0, quad, inv_s2, lnsig, m, K);
+                if (p.w) {
+                    if (!p.no_llk) sc_llk += wgt * (m > 0 ? lk0 - 0.5 * Posterior<K>::logdet(pm, pe) : 0.0);
+                } else {
+                    const bool use = m > 0 && row < n;  // wgt is 1 for real rows
+                    sc_llk += use ? lk0 : 0.0;
+                    int e;
+                    scl[L_PM + i] = frexp(run_pm * (use ? pm : 1.0), &e);
+                    scl[L_PX + i] = run_px + (double)(e + (use ? pe : 0));
+                }
+                sc_w += wgt;
+                scl[L_DEV + i] = run_dev + sc_dev;
+                scl[L_LLK + i] = run_llk + sc_llk;
+                scl[L_W + i] = run_w + sc_w;
+                scl[L_NE + i] = run_ne + sc_ne;
+            }
+            scl[wave * SQW + lane] = sq_run + sc_sq;
+        }
+        __syncthreads();  // W rows of this parity are final: the accumulator waves start P4b(tile)
+        // ------------------------------------------------------------ P4a: cross / sumx += X~^T [wz | w]
+        // the only reader of the x~ tile; the next tile's rows are requested one per k-step behind the MFMAs
+        {
+            load_pair(qbA, 6);  // the next tile's first digit pair (the table does not depend on the tile)
+            double bzb[2], axb[2][RT];
+            bzb[0] = Wsc[l4 * WS + 16 * NTP + l15];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) axb[0][r] = Xs[l4 * XS + DW * wave + 16 * r + l15];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s < RPW) load_row(tile + 1, s);  // unconditional (clamped rows)
+                if (s + 1 < 8) {
+                    const int smp = 4 * (s + 1) + l4;
+                    bzb[(s + 1) & 1] = Wsc[smp * WS + 16 * NTP + l15];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) axb[(s + 1) & 1][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s & 1][r], bzb[s & 1], accX[r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        front_barrier(bar, bar_target, lane_entry);  // the x~ tile is free
+        // ------------------------------------------------------------ P1 of the next tile
+        stage_tile(tile + 1, lane, par ^ 1);
+        front_barrier(bar, bar_target, lane_entry);
+    }
+
+    // ---------------------------------------------------------------- epilogue (front waves)
+    {
+        const int lane = lane_entry, l15 = lane & 15, l4 = lane >> 4;
+        const double sq_w = wave_sum(scl[wave * SQW + lane]);
+        const double xx_w = wave_sum(xx_run);
+        if (lane == 0) {
+            xxs[wave] = sq_w;
+            xxs[NF + wave] = xx_w;
+        }
+        front_barrier(bar, bar_target, lane_entry);
+        StatsLayout L(d, K);
+        double *out = p.part + (int64_t)blockIdx.x * L.len;
+        if (wave == 0) {
+            double v0 = 0.0, xx_tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NF; ++w) v0 += xxs[w];
+#pragma unroll
+            for (int w = 0; w < NF; ++w) xx_tot += xxs[NF + w];
+            const int li = lane < B ? lane : 0;
+            double sc_llk = scl[L_LLK + li];
+            sc_llk -= 0.5 * (log(scl[L_PM + li]) + scl[L_PX + li] * LN_2);
+            const double v1 = wave_sum(lane < B ? scl[L_DEV + li] : 0.0), v2 = wave_sum(lane < B ? sc_llk : 0.0),
+                         v3 = wave_sum(lane < B ? scl[L_W + li] : 0.0), v4 = wave_sum(lane < B ? scl[L_NE + li] : 0.0);
+            if (lane == 0) {
+                double *sc = out + L.scalars;
+                sc[SC_SQERR] = v0;
+                sc[SC_DEVSQ] = v1 + xx_tot;
+                sc[SC_LLK] = v2 - 0.5 * inv_s2 * xx_tot;
+                sc[SC_SUMW] = v3;
+                sc[SC_NONEMPTY] = v4;
+                sc[5] = 0.0;
+                sc[6] = 0.0;
+                sc[7] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int dim = DW * wave + 16 * r + l4 + 4 * q;
+                if (dim >= d) continue;
+                if (l15 < K) out[L.cross + (int64_t)dim * K + l15] = accX[r][q];
+                else if (l15 == K) out[L.sumx + dim] = accX[r][q];
+            }
+    }
+}
+
+// ------------------------------------------------------------------ launcher
+template <int K>
+static hipError_t launch_roles_t(int grid, const PassArgs &a, hipStream_t s) {
+    const size_t lds = sizeof(double) * CfgR<K>::LDS_DOUBLES;
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&em_roles_kernel<K>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((em_roles_kernel<K>), dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_em_roles(int k, int grid, const PassArgs &a, hipStream_t s) {
+    switch (k) {
+#ifdef PPCA_DEV_K10
+        case 10: return launch_roles_t<10>(grid, a, s);
+#else
+        case 1: return launch_roles_t<1>(grid, a, s);
+        case 2: return launch_roles_t<2>(grid, a, s);
+        case 3: return launch_roles_t<3>(grid, a, s);
+        case 4: return launch_roles_t<4>(grid, a, s);
+        case 5: return launch_roles_t<5>(grid, a, s);
+        case 6: return launch_roles_t<6>(grid, a, s);
+        case 7: return launch_roles_t<7>(grid, a, s);
+        case 8: return launch_roles_t<8>(grid, a, s);
+        case 9: return launch_roles_t<9>(grid, a, s);
+        case 10: return launch_roles_t<10>(grid, a, s);
+#endif
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ppca

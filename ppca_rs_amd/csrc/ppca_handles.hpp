@@ -43,6 +43,10 @@ struct ppca_ctx {
     size_t qtab_cap = 0;
     BufRef gws;   // workspace of the generic split pipeline
     size_t gws_cap = 0;
+    // mixture scratch, kept across iterations (hipMalloc / hipFree of hundreds of MB per component cost more than
+    // the kernels): 0 llk, 1 u, 2 lse, 3 log posteriors, 4 component weights, 5 row list, 6 block counts
+    BufRef mix[7];
+    size_t mix_cap[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 struct ppca_dataset {

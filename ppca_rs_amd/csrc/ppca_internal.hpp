@@ -24,6 +24,7 @@ struct PassArgs {
     const double *X;      // n x d row-major, non-finite = masked
     int64_t ldx;          // row stride in elements
     const double *w;      // n weights or nullptr (= 1)
+    const int *rows;      // EM mode, nullable: gathered pass -- sample i is physical row rows[i] of X (w is indexed by i)
     int64_t n;
     int d;
     const double *model;  // device model buffer
@@ -57,6 +58,9 @@ int fused_gram_tiles(int k);  // number of qflag entries the guard writes for st
 // Launchers.  Return hipSuccess or the launch error.
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s);
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);
+// The EM pass as an 8-wave workgroup with front / accumulator roles (ppca_em_roles.hip); honours a.qflag like the
+// int8 instantiation of pass_kernel (returns at once when the guard selects the fp64 Gram).
+hipError_t launch_em_roles(int k, int grid, const PassArgs &a, hipStream_t s);
 hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s);
 hipError_t launch_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
                            int has_ig, double alpha, double beta, hipStream_t s);
@@ -92,5 +96,10 @@ hipError_t launch_reduce_max(const double *v, int64_t n, double *out_scalar, dou
 hipError_t launch_exp_shift(const double *v, const double *max_dev, int64_t n, double *out, hipStream_t s);
 hipError_t launch_reduce_sum(const double *v, const double *w, int64_t n, double *out_scalar, double *work,
                              hipStream_t s);
+// rows[0 .. m) = ascending indices i with exp(v[i] - *shift_dev) > 0, wout[0 .. m) those weights, counts[select_blocks(n)] = m
+// (counts: select_blocks(n) + 1 ints of scratch).
+hipError_t launch_select_positive(const double *v, const double *shift_dev, int64_t n, int *counts, int *rows, double *wout,
+                                  hipStream_t s);
+int select_blocks(int64_t n);
 
 }  // namespace ppca

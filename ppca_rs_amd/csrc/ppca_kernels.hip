@@ -24,101 +24,9 @@
 #include <type_traits>
 #include <utility>
 
-#include "ppca_internal.hpp"
+#include "ppca_device.hpp"
 
 namespace ppca {
-
-typedef double d4_t __attribute__((ext_vector_type(4)));
-
-template <int K>
-struct Cfg {
-    static constexpr int KP = K * (K + 1) / 2;
-    static constexpr int NTP = (KP + 15) / 16;  // column tiles holding vech(P)
-    static constexpr int NTM = NTP + 1;         // + the [w z | w] tile
-    static constexpr int B = FUSED_TILE;
-    static constexpr int DP = FUSED_MAX_D;
-    static constexpr int XS = DP + 2;           // x~ tile row stride (doubles): conflict-free A-operand reads
-    static constexpr int CS = K + 1;            // C tile row stride; column K is all zeros
-    static constexpr int GS = 16 * NTM + 1;     // [G | b] exchange row stride
-    static constexpr int WS = 16 * NTM + 2;     // [wP | wz | w] row stride
-    static constexpr int OFF_X = 0;
-    static constexpr int OFF_C = OFF_X + B * XS;
-    static constexpr int OFF_G = OFF_C + DP * CS;
-    static constexpr int OFF_W = OFF_G + 2 * B * GS;
-    static constexpr int OFF_M = OFF_W + B * WS;  // mask words, B x 4 u64
-    static constexpr int OFF_S = OFF_M + 2 * B * 4;  // (two parities: the next tile is staged behind P4)
-                                                     // then xx[B] doubles, m[B] ints
-    // running per-solver-lane scalars (kept out of registers: at this pressure hipcc parks loop-carried
-    // once-per-tile values in scratch and reloads them with an exposed vmcnt(0)):
-    // sq[NW <= 8 waves][B] | dev[B] | llk[B] | sumw[B] | nonempty[B] | det mantissa[B] | det exponent[B]
-    static constexpr int OFF_L = OFF_S + 2 * B;
-    static constexpr int LDS_DOUBLES = OFF_L + 22 * B;  // (sq has two slots per solver sample when the waves pair lanes)
-};
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// Wave-wide sum on the DPP data path (VALU speed, no LDS crossbar): quad swaps, half-row and row mirrors,
-// then row_bcast15 / row_bcast31 carry the row totals forward; lane 63 ends up with the total, which is
-// returned as a wave-uniform value.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double wave_total(double v) {
-    v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
-    v += dpp_f64<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
-    v += dpp_f64<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
-    v += dpp_f64<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 = total
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-
-// dst[LANE] = sval (wave-uniform value into ONE lane of a VGPR): no compare mask, no select.  The lane
-// select is an immediate: the instruction admits a single SGPR operand (constant-bus limit).
-template <int LANE>
-__device__ __forceinline__ int writelane(int dst, int sval) {
-    // s_nop 1: gfx940+ needs 2 wait states between a VALU that writes an SGPR (the v_cmp ballot) and a
-    // VALU that reads it; hipcc pads its own code but nothing inside an asm statement.
-    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
-    return dst;
-}
-// As writelane, for a value produced by the SCALAR unit (no VALU-writes-SGPR hazard to pad).
-template <int LANE>
-__device__ __forceinline__ int writelane_s(int dst, int sval) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
-    return dst;
-}
-// mask bit of the lane ? v : 0.0 with the wave mask taken straight from its SGPR pair (a C++ select on
-// (mask >> lane) & 1 would rebuild the predicate with vector shifts).
-__device__ __forceinline__ double keep_if(double v, unsigned long long mask) {
-    const long long b = __double_as_longlong(v);
-    int lo, hi;
-    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(lo) : "v"((int)b), "s"(mask));
-    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(hi) : "v"((int)(b >> 32)), "s"(mask));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
 
 // ------------------------------------------------------------------ int8-sliced Gram operand
 // G_i = sum_j m_ij vech(c_j c_j^T) has one EXACT operand (the 0/1 mask), so the other one can be
@@ -128,12 +36,6 @@ __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
 // E_c = exponent of max_j |Q[j][c]| (|Q| < 2^E_c).  QS balanced digits span (-0.504, +0.496) 128^QS, so
 // the integers are kept below 2^(7 QS - 2): with QS = 8 that is 54 bits under the column maximum,
 // finer than the fp64 rounding of the products themselves.
-constexpr int QS = 8;
-typedef int i4_t __attribute__((ext_vector_type(4)));
-
-template <int K>
-constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
-
 // qtab: [NTP][QS][4 k-chunks][64 lanes][16 bytes]; lane = 16 (dim/16 % 4) + (col % 16), byte = dim % 16
 // qscale: [64] dequantisation multipliers 2^(E_c - (7 QS - 2)).
 // One workgroup per packed-column tile t (256 threads).  Step 1, thread = dim: maxima of the tile's 16 columns
@@ -259,7 +161,10 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
 // NW = waves per workgroup: 4 (one wave per SIMD, 512 registers each) or 8 (two waves per SIMD,
 // 256 registers each, every wave owning half as many accumulator tiles).
 // GI8: Gram on the int8 MFMA (wave t <-> packed-column tile t) instead of fp64 MFMA.
-template <int K, bool EM, int NW, bool GI8>
+// GATHER: the pass honours PassArgs::rows (sample i = physical row rows[i]); the fp64-Gram instantiations always do
+// (they are the fallback of both forms), the tuned int8 instantiation only as its own variant, so that the
+// un-gathered hot kernel carries no trace of it.
+template <int K, bool EM, int NW, bool GI8, bool GATHER = false>
 __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     using cfg = Cfg<K>;
     constexpr int KP = cfg::KP, NTP = cfg::NTP, NTM = cfg::NTM, B = cfg::B, XS = cfg::XS, CS = cfg::CS,
@@ -384,6 +289,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     const int64_t nleft = n - tile_begin * B;
     const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));  // rows from the workgroup's first row to the end
     const double *Xwg = p.X + tile_begin * B * p.ldx;
+    constexpr bool CAN_GATHER = EM && NW == 4 && (GATHER || !GI8);
+    const int *rows_wg = (CAN_GATHER && p.rows) ? p.rows + tile_begin * B : nullptr;
     const int lane_entry = lane;
     // Row loads are buffer loads through a per-row descriptor (base = row start, extent = d doubles): the
     // address is one scalar multiply-add, the lane offset one constant VGPR, the quarter an immediate --
@@ -392,8 +299,13 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     auto load_row = [&](int64_t tile, int r) {
         const int rel = (int)(tile - tile_begin) * B + wave * RPW + r;
         const int rc = rel < nrel ? rel : nrel - 1;
-        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<double *>(Xwg + (int64_t)rc * p.ldx), 0, d * (int)sizeof(double), 0x00020000);
+        // gathered pass (PassArgs::rows): sample i of the pass is physical row rows[i] -- one scalar load per row
+        const double *rowp = Xwg + (int64_t)rc * p.ldx;
+        if constexpr (CAN_GATHER) {
+            if (rows_wg) rowp = p.X + (int64_t)rows_wg[rc] * p.ldx;
+        }
+        const __amdgpu_buffer_rsrc_t xrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rowp), 0, d * (int)sizeof(double), 0x00020000);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // validity is applied when consumed (P1)
             typedef unsigned u4_t __attribute__((ext_vector_type(4)));
@@ -1331,6 +1243,78 @@ __global__ void exp_shift_kernel(const double *v, const double *mx, int64_t n, d
     if (i < n) out[i] = exp(v[i] - *mx);
 }
 
+// ------------------------------------------------------------------ responsibility-sparse component passes
+// Per mixture component the sample weights are exp(u_i - max) (mix.rs:320-323): the largest is exactly 1.  Every
+// statistic is a sum of weight x per-sample term, so a sample whose weight is below 2^-200 (6e-61) of the largest
+// moves no statistic: its term is >= 147 binary orders below the fp64 resolution of the sum it would join (the
+// exponential underflows to exactly zero only past 2^-1074; at d = 256 most samples of the other clusters sit far
+// below either bound).  Such samples are dropped from the component's pass.
+// select_*: ascending list of the rows with a non-zero weight and their weights, in three deterministic steps
+// (per-block counts, exclusive scan of the counts, ordered scatter); the EM pass then gathers those rows.
+constexpr int SEL_BLOCK = 256;
+constexpr double SEL_MIN_WEIGHT = 6.223015277861142e-61;  // 2^-200
+__global__ __launch_bounds__(SEL_BLOCK) void select_count_kernel(const double *v, const double *shift, int64_t n, int *counts) {
+    const int64_t i = (int64_t)blockIdx.x * SEL_BLOCK + threadIdx.x;
+    const bool keep = i < n && exp(v[i] - *shift) > SEL_MIN_WEIGHT;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    __shared__ int wc[SEL_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+// counts[0 .. nblocks) -> exclusive offsets in place; counts[nblocks] = total.  One workgroup.
+__global__ __launch_bounds__(1024) void select_scan_kernel(int *counts, int nblocks) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = t * per, b1 = (b0 + per < nblocks) ? b0 + per : nblocks;
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += counts[b];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan of the per-thread sums
+        const int add = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int b = b0; b < b1; ++b) {
+        const int c = counts[b];
+        counts[b] = run;
+        run += c;
+    }
+    if (t == 1023) counts[nblocks] = part[1023];
+}
+__global__ __launch_bounds__(SEL_BLOCK) void select_scatter_kernel(const double *v, const double *shift, int64_t n,
+                                                                    const int *offsets, int *rows, double *wout) {
+    const int64_t i = (int64_t)blockIdx.x * SEL_BLOCK + threadIdx.x;
+    const double w = i < n ? exp(v[i] - *shift) : 0.0;
+    const bool keep = w > SEL_MIN_WEIGHT;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    __shared__ int wc[SEL_BLOCK / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wc[wave] = __popcll(bal);
+    __syncthreads();
+    int base = offsets[blockIdx.x];
+    for (int u = 0; u < wave; ++u) base += wc[u];
+    if (keep) {
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        rows[pos] = (int)i;
+        wout[pos] = w;
+    }
+}
+hipError_t launch_select_positive(const double *v, const double *shift_dev, int64_t n, int *counts, int *rows, double *wout,
+                                  hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int nblocks = (int)((n + SEL_BLOCK - 1) / SEL_BLOCK);
+    hipLaunchKernelGGL(select_count_kernel, dim3(nblocks), dim3(SEL_BLOCK), 0, s, v, shift_dev, n, counts);
+    hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, s, counts, nblocks);
+    hipLaunchKernelGGL(select_scatter_kernel, dim3(nblocks), dim3(SEL_BLOCK), 0, s, v, shift_dev, n, counts, rows, wout);
+    return hipGetLastError();
+}
+int select_blocks(int64_t n) { return (int)((n + SEL_BLOCK - 1) / SEL_BLOCK); }
+
 // ------------------------------------------------------------------ launchers
 int fused_grid(int64_t n, int n_cu) {
     int64_t tiles = (n + FUSED_TILE - 1) / FUSED_TILE;
@@ -1351,25 +1335,25 @@ size_t fused_lds_bytes(int k) {
 }
 
 // hipFuncSetAttribute is per device: remember which devices have seen it for this instantiation.
-template <int K, bool EM, int NW, bool GI8>
+template <int K, bool EM, int NW, bool GI8, bool GATHER = false>
 static hipError_t pass_attr(size_t lds) {
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM, NW, GI8>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pass_kernel<K, EM, NW, GI8, GATHER>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     done.fetch_or(bit, std::memory_order_release);
     return hipSuccess;
 }
 
-template <int K, bool EM, int NW, bool GI8>
+template <int K, bool EM, int NW, bool GI8, bool GATHER = false>
 static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
     const size_t lds = sizeof(double) * Cfg<K>::LDS_DOUBLES;
-    if (hipError_t e = pass_attr<K, EM, NW, GI8>(lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((pass_kernel<K, EM, NW, GI8>), dim3(grid), dim3(64 * NW), lds, s, a);
+    if (hipError_t e = pass_attr<K, EM, NW, GI8, GATHER>(lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL((pass_kernel<K, EM, NW, GI8, GATHER>), dim3(grid), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1394,6 +1378,16 @@ static int gram_mode() {
     return v;
 }
 
+// PPCA_EM_ROLES=1 selects the role-split 8-wave EM kernel (ppca_em_roles.hip): bit-identical statistics, measured
+// 71.2 vs 71.8 EM it/s at N = 10 M -- kept as a measured alternative, see the note at the top of that file.
+static bool em_roles() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_EM_ROLES");
+        return e && atoi(e) == 1;
+    }();
+    return v;
+}
+
 // Slice table + guard flags of the current model (device-side, no host sync), then the pass: the int8 variant and,
 // behind the guard, the fp64 variant -- each returns at once unless qflag selects it.
 template <int K, bool EM>
@@ -1408,14 +1402,23 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
     }
 #endif
     hipLaunchKernelGGL((qprep_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab, a.qflag);
+    // EM pass: the role-split 8-wave kernel (ppca_em_roles.hip) when PPCA_EM_ROLES=1
+    const bool roles = EM && em_roles() && !a.rows;
+    auto int8_pass = [&](const PassArgs &b) {
+        if (roles) return launch_em_roles(K, grid, b, s);
+        if constexpr (EM) {
+            if (b.rows) return launch_pass_t<K, EM, 4, true, true>(grid, b, s);
+        }
+        return launch_pass_t<K, EM, 4, true>(grid, b, s);
+    };
     if (mode == 2) {
         a.qflag = nullptr;
-        return launch_pass_t<K, EM, 4, true>(grid, a, s);
+        return int8_pass(a);
     }
 #ifdef PPCA_DEV_K10
     return hipErrorInvalidValue;
 #else
-    if (hipError_t e = launch_pass_t<K, EM, 4, true>(grid, a, s); e != hipSuccess) return e;
+    if (hipError_t e = int8_pass(a); e != hipSuccess) return e;
     return launch_pass_t<K, EM, 4, false>(grid, a, s);
 #endif
 }

@@ -234,22 +234,16 @@ class _DeviceMixBackend:
         return mx.value
 
     def accumulate(self, c: int, shift: float):
-        """weights exp(u_c - shift), their sum, and the component's weighted statistics (device tensor view)."""
+        """weights exp(u_c - shift), their sum, and the component's weighted statistics (device tensor view); rows whose
+        weight is exactly zero are skipped by the pass (ppca_mix_component_stats)."""
         view = self.stats[c * self.L:(c + 1) * self.L]
         if self.n == 0:
             view.zero_()
             return 0.0, view
-        check(lib().ppca_vector_exp_shift_dev(self.ctx.handle, C.c_void_p(self.u.data_ptr() + 8 * c * self.n), shift, self.n,
-                                              C.c_void_p(self.wc.data_ptr())))
         s = C.c_double(0.0)
-        check(lib().ppca_vector_sum_dev(self.ctx.handle, C.c_void_p(self.wc.data_ptr()), None, self.n, C.byref(s)))
-        h = C.c_void_p()
-        check(lib().ppca_dataset_with_weights(self.shard._h, None, C.c_void_p(self.wc.data_ptr()), C.byref(h)))
-        try:
-            check(lib().ppca_em_accumulate(self.ctx.handle, h, self.cur[c].h, C.c_void_p(view.data_ptr())))
-            self.ctx.synchronize()
-        finally:
-            lib().ppca_dataset_free(h)
+        check(lib().ppca_mix_component_stats(self.ctx.handle, self.shard._h, self.cur[c].h,
+                                             C.c_void_p(self.u.data_ptr() + 8 * c * self.n), shift,
+                                             C.c_void_p(view.data_ptr()), C.byref(s), None))
         return s.value, view
 
     def pack(self, extras: np.ndarray):

@@ -16,7 +16,8 @@ ds = P.Dataset.concat(parts)
 del parts
 mix = P.PPCAMix.init(nm, k, ds, seed=7)
 prev = -np.inf
-for it in range(4):
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+for it in range(iters):
     ctx.synchronize(); t0 = time.perf_counter()
     mix, llk = mix.iterate_with_llk(ds)
     ctx.synchronize(); dt = time.perf_counter() - t0
