@@ -13,13 +13,25 @@
 // Chunk results are accumulated in chunk order (deterministic).  Correctness first: the
 // GEMM is a plain LDS-staged 64x64 tile kernel on v_mfma_f64_16x16x4_f64.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "ppca_internal.hpp"
 
 namespace ppca {
 
 typedef double d4g_t __attribute__((ext_vector_type(4)));
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_g_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for_g(F &&f) {
+    static_for_g_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ double gwave_sum(double v) {
 #pragma unroll
@@ -90,12 +102,16 @@ struct GemmArgs {
     // part + z * M * N (then splitk_reduce_kernel adds the partials to the outputs in slice order)
     int64_t kslice;
     double *part;
+    // device-side selection between this fp64 contraction and its int8-sliced twin: run only if *guard == run_if
+    const int *guard;
+    int run_if;
 };
 
 template <int AMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ double As[64][17];
     __shared__ double Bs[16][65];
+    if (g.guard && *g.guard != g.run_if) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
@@ -190,6 +206,310 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 }
             }
         }
+}
+
+
+// ------------------------------------------------------------------ int8-sliced exact contractions
+// Both large contractions of the pass have one EXACT operand, the 0/1 mask:
+//     G[i][c] = sum_j m_ij Q[j][c]        (samples x k', over the d dims)
+//     S[j][c] = sum_i m_ij (wP)[i][c]     (d x k', over the samples of a chunk)
+// so, as in the fused kernel (ppca_kernels.hip, qprep_kernel), the other operand is cut into QS = 8 signed 7-bit
+// digits of a per-column fixed-point form (54 bits below the column maximum) and contracted on
+// v_mfma_i32_16x16x64_i8 with exact integer accumulation -- 8 slices x 1/64 of the fp64 MFMA's cycles per
+// multiply-add.  The digit sums are folded into fp64 once per output element (Horner).  Dynamic-range guards decide on
+// the DEVICE, per model (Gram) and per chunk (S), whether the int8 form or the fp64-MFMA GEMM runs (both are
+// enqueued; the loser returns at once):
+//   Gram: the fused kernel's rule (forward bound K d eps <= 1e-8 sigma^2 or backward bound K^2 eps <= 2^-40 r_min)
+//   S:    column maximum of |wP| over the chunk <= 2^20 x the column's mean |wP| -- then the absolute error of a
+//         sum, <= n 2^-55 max, stays below 2^-34 of the sum of the |terms|.
+constexpr int GQS = 8;
+typedef int gi4_t __attribute__((ext_vector_type(4)));
+
+// mask bytes of a chunk in both orientations: A[i][dpad] (row = sample) and AT[j][npad] (row = dim), zero padded
+__global__ __launch_bounds__(256) void gen_maskbytes_kernel(const double *X, int64_t ldx, int64_t n, int d, int dpad,
+                                                            int64_t npad, unsigned char *A, unsigned char *AT) {
+    __shared__ unsigned char tile[64][80];
+    const int t = threadIdx.x, r = t >> 2, q = t & 3;
+    const int64_t i0 = (int64_t)blockIdx.y * 64;
+    const int j0 = blockIdx.x * 64;
+    const int64_t row = i0 + r;
+    union { unsigned char b[16]; gi4_t v; } u;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int j = j0 + 16 * q + e;
+        u.b[e] = (row < n && j < d && __builtin_isfinite(X[row * ldx + j])) ? 1 : 0;
+    }
+    if (row < npad) *reinterpret_cast<gi4_t *>(A + row * dpad + j0 + 16 * q) = u.v;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tile[r][16 * q + e] = u.b[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) u.b[e] = tile[16 * q + e][r];
+    *reinterpret_cast<gi4_t *>(AT + (int64_t)(j0 + r) * npad + i0 + 16 * q) = u.v;  // dims up to dpad: zeros
+}
+
+// smallest non-zero squared row norm of C (guard of the Gram digits); one workgroup
+__global__ __launch_bounds__(256) void gen_rmin_kernel(const double *model, int d, int k, double *rmin_out, int *flags) {
+    __shared__ unsigned long long best;
+    if (threadIdx.x == 0) best = 0x7FF0000000000000ull;
+    __syncthreads();
+    for (int j = threadIdx.x; j < d; j += 256) {
+        double rn = 0.0;
+        for (int a = 0; a < k; ++a) {
+            const double c = model[MODEL_HDR + (int64_t)j * k + a];
+            rn += c * c;
+        }
+        if (rn > 0.0 && rn < 1.0e300) atomicMin(&best, (unsigned long long)__double_as_longlong(rn));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *rmin_out = __longlong_as_double((long long)best);
+        flags[0] = 0;
+    }
+}
+
+// digits of Q = vech(c c^T): one workgroup per packed column c; planes BtQ[s][c][dpad], scale[c]
+__global__ __launch_bounds__(256) void gen_qdigits_kernel(const double *model, int d, int k, int dpad, int kp,
+                                                          const double *rmin, double *scale, signed char *BtQ, int *flags) {
+    __shared__ unsigned long long cmax;
+    __shared__ int bad;
+    const int c = blockIdx.x, t = threadIdx.x;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= c) ++a;
+    const int b = c - a * (a + 1) / 2;
+    if (t == 0) {
+        cmax = 0ull;
+        bad = 0;
+    }
+    __syncthreads();
+    double mx = 0.0;
+    int notfin = 0;
+    for (int j = t; j < d; j += 256) {
+        const double q = fabs(model[MODEL_HDR + (int64_t)j * k + a] * model[MODEL_HDR + (int64_t)j * k + b]);
+        if (!(q < 1.0e300)) notfin = 1;
+        else mx = fmax(mx, q);
+    }
+    if (mx > 0.0) atomicMax(&cmax, (unsigned long long)__double_as_longlong(mx));
+    if (notfin) atomicOr(&bad, 1);
+    __syncthreads();
+    const double cm = __longlong_as_double((long long)cmax);
+    int e = 0;
+    if (cm > 0.0) (void)frexp(cm, &e);
+    const double sc = ldexp(1.0, e - (7 * GQS - 2));
+    if (t == 0) {
+        scale[c] = sc;
+        int unsafe = bad;
+        if (cm > 0.0) {
+            const double eps = 0.5 * sc, s2 = model[1];
+            const bool fwd = (double)k * (double)d * eps <= 1.0e-8 * s2;
+            const bool bwd = (double)k * (double)k * eps <= 9.094947017729282e-13 * *rmin;
+            if (!(fwd || bwd)) unsafe = 1;
+        }
+        if (unsafe) atomicOr(&flags[0], 1);
+    }
+    const int shift = (7 * GQS - 2) - e;
+    for (int j = t; j < dpad; j += 256) {
+        double q = 0.0;
+        if (j < d) q = model[MODEL_HDR + (int64_t)j * k + a] * model[MODEL_HDR + (int64_t)j * k + b];
+        if (!(fabs(q) < 1.0e300)) q = 0.0;
+        long long I = llrint(ldexp(q, shift));
+#pragma unroll
+        for (int sl = 0; sl < GQS; ++sl) {
+            const int dig = (int)((I + 64) & 127) - 64;
+            I = (I - dig) >> 7;
+            BtQ[((int64_t)sl * kp + c) * dpad + j] = (signed char)dig;
+        }
+    }
+}
+
+// per column of V[n][kp]: maximum and sum of |v| over a block of 256 rows -> part[block][2][kp]
+__global__ __launch_bounds__(256) void gen_colstat_kernel(const double *V, int64_t n, int kp, double *part, int *flags) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) flags[1] = 0;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= kp) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = (r0 + 256 < n) ? r0 + 256 : n;
+    double mx = 0.0, sm = 0.0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const double v = fabs(V[r * kp + c]);
+        mx = fmax(mx, v);   // (a NaN leaves the maximum alone; the sum below carries it into the guard)
+        sm += v;
+    }
+    part[((int64_t)blockIdx.y * 2) * kp + c] = mx;
+    part[((int64_t)blockIdx.y * 2 + 1) * kp + c] = sm;
+}
+// -> scale[c] and the chunk's guard flag (flags[1], reset by gen_colstat_kernel); sums in block order (deterministic)
+__global__ __launch_bounds__(256) void gen_colscale_kernel(const double *part, int nblocks, int64_t n, int kp, double *scale,
+                                                           int *flags) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= kp) return;
+    double mx = 0.0, sm = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        mx = fmax(mx, part[((int64_t)b * 2) * kp + c]);
+        sm += part[((int64_t)b * 2 + 1) * kp + c];
+    }
+    int e = 0;
+    if (mx > 0.0 && mx < 1.0e300) (void)frexp(mx, &e);
+    scale[c] = ldexp(1.0, e - (7 * GQS - 2));
+    // finite, and the maximum within 2^20 of the mean magnitude
+    if (!(sm < 1.0e300) || !(mx * (double)n <= 1048576.0 * sm)) atomicOr(&flags[1], 1);
+}
+// digits of V[n][kp] (row-major) -> planes BtW[s][c][npad] (samples contiguous): 64 samples x 64 columns per workgroup
+__global__ __launch_bounds__(256) void gen_wdigits_kernel(const double *V, int64_t n, int kp, int64_t npad, const double *scale,
+                                                          signed char *BtW, const int *flags) {
+    __shared__ signed char tile[GQS][64][80];
+    if (flags[1]) return;
+    const int t = threadIdx.x, r = t >> 2, q = t & 3;
+    const int64_t i0 = (int64_t)blockIdx.y * 64;
+    const int c0 = blockIdx.x * 64;
+    const int64_t row = i0 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = c0 + 16 * q + e;
+        double v = 0.0;
+        int shift = 0;
+        if (row < n && c < kp) {
+            v = V[row * kp + c];
+            int ex;
+            (void)frexp(scale[c], &ex);  // scale = 2^(ex - 1)
+            shift = -(ex - 1);
+        }
+        long long I = llrint(ldexp(v, shift));
+#pragma unroll
+        for (int sl = 0; sl < GQS; ++sl) {
+            const int dig = (int)((I + 64) & 127) - 64;
+            I = (I - dig) >> 7;
+            tile[sl][16 * q + e][r] = (signed char)dig;
+        }
+    }
+    __syncthreads();
+    // 8 slices x 64 columns x 4 pieces of 16 samples
+    for (int idx = t; idx < GQS * 64 * 4; idx += 256) {
+        const int piece = idx & 3, cc = (idx >> 2) & 63, sl = idx >> 8;
+        const int c = c0 + cc;
+        if (c >= kp) continue;
+        union { signed char b[16]; gi4_t v; } u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u.b[e] = tile[sl][cc][16 * piece + e];
+        *reinterpret_cast<gi4_t *>(BtW + ((int64_t)sl * kp + c) * npad + i0 + 16 * piece) = u.v;
+    }
+}
+
+// C[M x N] (+)= scale[c] * sum_s 128^s ( A[M x K] . Bt[s][N x K]^T ), bytes, K a multiple of 64.
+// Workgroup tile 128 rows x 32 columns x 8 slices; wave w: rows 32 w .. +31 (two 16-row tiles) x two 16-column
+// tiles x 8 slices = 32 accumulator tiles.  Operands of K-step k+1 are fetched into registers before the MFMAs of
+// step k and go to the other LDS buffer after them.
+struct I8GemmArgs {
+    const unsigned char *A;
+    int64_t lda;
+    const signed char *Bt;
+    int64_t ldb;      // bytes per column row of one plane
+    int64_t plane;    // bytes between slices
+    int64_t M, N, K;
+    const double *scale;
+    double *out;
+    int64_t ldo;
+    int accumulate;
+    const int *guard;  // run only if *guard == 0
+};
+
+// KB = bytes of K per staged step (64 or 128: whole 128-byte lines per row at 128); rows padded by 16 B in LDS.
+template <int KB>
+__global__ __launch_bounds__(256) void i8gemm_kernel(I8GemmArgs g) {
+    constexpr int RS = KB + 16, PR = KB / 16;           // LDS row stride, 16-byte pieces per row
+    constexpr int NA = 128 * PR / 256, NB = GQS * 32 * PR / 256;  // pieces per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char i8sm[];
+    unsigned char *As = i8sm;                              // [2][128][RS]
+    unsigned char *Bs = i8sm + 2 * 128 * RS;               // [2][GQS * 32][RS]
+    if (g.guard && *g.guard != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // (an XCD-aware order of the tiles -- column block c pinned to XCD c % 8, row blocks of one column block side by
+    //  side -- measured SLOWER, 106 vs 97 ms per iteration at N = 400 k, d = 1024, k = 64: plain 2-D order kept)
+    const int64_t m0 = (int64_t)blockIdx.y * 128;
+    const int64_t n0 = (int64_t)blockIdx.x * 32;
+    gi4_t acc[2][2][GQS];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s = 0; s < GQS; ++s) acc[a][b][s] = gi4_t{0, 0, 0, 0};
+    gi4_t ra[NA], rb[NB];
+    auto fetch = [&](int64_t k0) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int piece = tid + 256 * u, r = piece / PR, q = piece % PR;
+            const int64_t row = m0 + r;
+            ra[u] = (row < g.M && k0 + 16 * q < g.K) ? *reinterpret_cast<const gi4_t *>(g.A + row * g.lda + k0 + 16 * q)
+                                                     : gi4_t{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int piece = tid + 256 * u, q = piece % PR, rr = piece / PR, cc = rr & 31, sl = rr >> 5;
+            const int64_t col = n0 + cc;
+            rb[u] = (col < g.N && k0 + 16 * q < g.K)
+                        ? *reinterpret_cast<const gi4_t *>(g.Bt + sl * g.plane + col * g.ldb + k0 + 16 * q)
+                        : gi4_t{0, 0, 0, 0};
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int piece = tid + 256 * u;
+            *reinterpret_cast<gi4_t *>(As + (buf * 128 + piece / PR) * RS + 16 * (piece % PR)) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int piece = tid + 256 * u;
+            *reinterpret_cast<gi4_t *>(Bs + (buf * GQS * 32 + piece / PR) * RS + 16 * (piece % PR)) = rb[u];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t k0 = 0; k0 < g.K; k0 += KB) {
+        const bool more = k0 + KB < g.K;
+        if (more) fetch(k0 + KB);
+#pragma unroll
+        for (int h = 0; h < KB / 64; ++h) {
+            gi4_t fa[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                fa[a] = *reinterpret_cast<const gi4_t *>(As + (buf * 128 + 32 * wave + 16 * a + l15) * RS + 64 * h + 16 * l4);
+#pragma unroll
+            for (int s = 0; s < GQS; ++s)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const gi4_t fb =
+                        *reinterpret_cast<const gi4_t *>(Bs + (buf * GQS * 32 + s * 32 + 16 * b + l15) * RS + 64 * h + 16 * l4);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        acc[a][b][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb, acc[a][b][s], 0, 0, 0);
+                }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t col = n0 + 16 * b + l15;
+        if (col >= g.N) continue;
+        const double sc = g.scale[col];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // C/D map of the 16x16 integer MFMA: row = 4 (lane >> 4) + reg
+                const int64_t row = m0 + 32 * wave + 16 * a + 4 * l4 + r;
+                if (row >= g.M) continue;
+                double v = (double)acc[a][b][GQS - 1][r];
+#pragma unroll
+                for (int s = GQS - 2; s >= 0; --s) v = v * 128.0 + (double)acc[a][b][s][r];
+                double *dst = g.out + row * g.ldo + col;
+                *dst = g.accumulate ? *dst + v * sc : v * sc;
+            }
+    }
 }
 
 // ------------------------------------------------------------------ wave-level SPD tools (runtime k <= 64)
@@ -484,9 +804,231 @@ __global__ __launch_bounds__(256) void solve_reg_kernel(SolveArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------ per-sample solve, LDS-broadcast form
+// As solve_reg_kernel (lane r keeps row r of M in registers, lane c column c of M^-1), but the wave-uniform operand
+// of every multiply-add -- L_cp in the trailing update, L_rt in the triangular solves -- comes from ONE uniform LDS
+// read (all lanes, same address: a broadcast) of the factor the lanes publish column by column, instead of two
+// v_readlane + the SGPR hazard wait per operand: the O(k^3) loops become "ds_read + v_fma" pairs that the LDS pipe
+// and the fp64 pipe run side by side.  A wave's LDS operations execute in order, so a column is readable right after
+// it is stored; no barrier.
+// op i of a flattened column-oriented substitution on a KxK factor: unknown t scaled (r == t) or unknown r updated
+// with unknown t; (lt, lr) = where its factor entry lives in Lm
+struct SubOp {
+    int t, r, lt, lr;
+};
+__host__ __device__ constexpr SubOp sub_op(int K, int i, bool fwd) {
+    if (fwd) {
+        int t = 0;
+        while (i >= K - t) {  // column t has 1 + (K - 1 - t) ops
+            i -= K - t;
+            ++t;
+        }
+        return SubOp{t, t + i, t, t + i};
+    }
+    int t = K - 1;
+    while (i >= 1 + t) {  // column t has 1 + t ops
+        i -= 1 + t;
+        --t;
+    }
+    if (i == 0) return SubOp{t, t, t, t};
+    return SubOp{t, i - 1, i - 1, t};
+}
+
+template <int KPAD>
+__global__ __launch_bounds__(256) void solve_bc_kernel(SolveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *Lm = gsm + (size_t)wave * KPAD * KPAD;  // Lm[p][r] = L_rp (p <= r); Lm[p][p] = 1 / L_pp
+    const int k = a.k, kp = k * (k + 1) / 2;
+    const double s2 = a.model[1], lnsig = a.model[2];
+    auto bcast = [&](double v, int src) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < a.n; i += stride) {
+        double *g = a.G + i * kp;
+        double *bz = a.Bz + i * (k + 1);
+        const bool live = lane < k;
+        double row[KPAD];
+        {
+            const double *grow = g + (live ? lane * (lane + 1) / 2 : 0);
+#pragma unroll
+            for (int t = 0; t < KPAD; ++t) {
+                double v = (t == lane) ? 1.0 : 0.0;            // identity padding
+                if (live && t <= lane) v = grow[t] + (t == lane ? s2 : 0.0);
+                row[t] = v;
+            }
+        }
+        const double bv = live ? bz[lane] : 0.0;
+        double mant = 1.0;
+        int ex = 0;
+        constexpr int CH = 8;
+        static_for_g<KPAD>([&](auto p_tag) {
+            constexpr int p = decltype(p_tag)::value;
+            const double piv = bcast(row[p], p);
+            const double rinv = 1.0 / sqrt(piv);
+            int e;
+            mant *= frexp(piv, &e);
+            ex += e;
+            row[p] = (lane == p) ? rinv : row[p] * rinv;
+            if (lane < KPAD) Lm[p * KPAD + lane] = row[p];
+            // row[c] -= L_lane,p * L_cp for c > p (lanes < c touch unused slots); the uniform operands arrive in groups
+            // of CH, the next group requested before the current one is consumed (fenced: hipcc otherwise hoists
+            // every read of the kernel to the top and spills them)
+            constexpr int NC = KPAD - 1 - p;
+            if constexpr (NC > 0) {
+                constexpr int NGC = (NC + CH - 1) / CH;
+                double bc[3][CH];
+                auto request = [&](auto g_tag) {
+                    constexpr int g = decltype(g_tag)::value;
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int o = g * CH + q;
+                        bc[g % 3][q] = Lm[p * KPAD + p + 1 + (o < NC ? o : NC - 1)];
+                    }
+                };
+                request(std::integral_constant<int, 0>{});
+                if constexpr (NGC > 1) request(std::integral_constant<int, 1>{});
+                static_for_g<NGC>([&](auto g_tag) {
+                    constexpr int g = decltype(g_tag)::value;
+                    if constexpr (g + 2 < NGC) request(std::integral_constant<int, g + 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int o = g * CH + q;
+                        if (o < NC) row[p + 1 + o] -= row[p] * bc[g % 3][q];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        });
+        const double logdet = log(mant) + (double)ex * LN_2;
+        // column `lane` of M^-1: L u = e_lane, then L^T x = u
+        // column-oriented substitutions (once an unknown is final, the updates of all the others are independent),
+        // each flattened into ONE stream of (uniform LDS operand, multiply-add) pairs -- the factor is static by now, so
+        // the operand requests run a fixed distance (two groups of GP) ahead of their use across column boundaries:
+        //   forward:  for t = 0 ..:      u_t *= 1/L_tt;  u_r -= L_rt u_t  (r > t)     operands Lm[t][t], Lm[t][r]
+        //   backward: for t = K-1 .. 0:  u_t *= 1/L_tt;  u_r -= L_tr u_t  (r < t)     operands Lm[t][t], Lm[r][t]
+        double u[KPAD];
+#pragma unroll
+        for (int r = 0; r < KPAD; ++r) u[r] = (r == lane) ? 1.0 : 0.0;
+        constexpr int NOPS = KPAD + KPAD * (KPAD - 1) / 2, GP = 8, NG = (NOPS + GP - 1) / GP;
+        auto stream = [&](auto fwd_tag) {
+            constexpr bool FWD = decltype(fwd_tag)::value;
+            double ring[3][GP];
+            auto request = [&](auto g_tag) {
+                constexpr int g = decltype(g_tag)::value;
+                static_for_g<GP>([&](auto q_tag) {
+                    constexpr int i = g * GP + decltype(q_tag)::value;
+                    constexpr SubOp op = sub_op(KPAD, i < NOPS ? i : NOPS - 1, FWD);
+                    ring[g % 3][decltype(q_tag)::value] = Lm[op.lt * KPAD + op.lr];
+                });
+            };
+            request(std::integral_constant<int, 0>{});
+            if constexpr (NG > 1) request(std::integral_constant<int, 1>{});
+            static_for_g<NG>([&](auto g_tag) {
+                constexpr int g = decltype(g_tag)::value;
+                if constexpr (g + 2 < NG) request(std::integral_constant<int, g + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                static_for_g<GP>([&](auto q_tag) {
+                    constexpr int i = g * GP + decltype(q_tag)::value;
+                    if constexpr (i < NOPS) {
+                        constexpr SubOp op = sub_op(KPAD, i, FWD);
+                        const double v = ring[g % 3][decltype(q_tag)::value];
+                        if constexpr (op.r == op.t) u[op.t] *= v;
+                        else u[op.r] -= v * u[op.t];
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        stream(std::true_type{});
+        stream(std::false_type{});
+        double z = 0.0, diag = 0.0;
+#pragma unroll
+        for (int r = 0; r < KPAD; ++r) {
+            z += u[r] * bcast(bv, r);
+            diag = (r == lane) ? u[r] : diag;
+        }
+        const double quad = gwave_sum(live ? bv * z : 0.0);
+        const double zz = gwave_sum(live ? z * z : 0.0);
+        const double tr = gwave_sum(live ? diag : 0.0);
+        const double wgt = a.w ? a.w[i] : 1.0;
+        const double xx = a.xx[i];
+        const int m = (int)a.mc[i];
+        const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, k);
+        if (a.em) {
+#pragma unroll
+            for (int r = 0; r < KPAD; ++r) {
+                const double zr = bcast(z, r);
+                if (live && r >= lane && r < k) g[r * (r + 1) / 2 + lane] = wgt * (zr * z + s2 * u[r]);
+            }
+            if (live) bz[lane] = wgt * z;
+            if (lane == 0) {
+                bz[k] = wgt;
+                double *sc = a.sc + i * 4;
+                sc[0] = m > 0 ? wgt * s2 * ((double)k - s2 * tr) : 0.0;
+                sc[1] = m > 0 ? wgt * (xx - quad - s2 * zz) : 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = m > 0 ? 1.0 : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPAD; ++r) {
+                const double sv = s2 * u[r];
+                if (live && r < k) {
+                    if (a.covs) a.covs[(i * k + r) * k + lane] = sv;
+                    if (r >= lane) g[r * (r + 1) / 2 + lane] = sv;
+                }
+            }
+            if (live) {
+                bz[lane] = z;
+                if (a.states) a.states[i * k + lane] = z;
+            }
+            if (lane == 0) {
+                double *sc = a.sc + i * 4;
+                sc[0] = 0.0;
+                sc[1] = 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = 0.0;
+                if (a.llks) a.llks[i] = lk;
+            }
+        }
+    }
+}
+
+template <int KPAD>
+static hipError_t launch_solve_bc(const SolveArgs &a, int grid, hipStream_t s) {
+    const size_t lds = sizeof(double) * 4 * KPAD * KPAD;
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (lds > 65536 && !(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_bc_kernel<KPAD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((solve_bc_kernel<KPAD>), dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
     int grid = (int)std::min<int64_t>((a.n + 3) / 4, (int64_t)n_cu);
     if (grid < 1) grid = 1;
+    static const bool reg = [] {  // PPCA_GENERIC_REG_SOLVE=1: the v_readlane-broadcast form (A/B runs)
+        const char *e = getenv("PPCA_GENERIC_REG_SOLVE");
+        return e && atoi(e) == 1;
+    }();
+    if (!reg) {
+        if (a.k <= 16) return launch_solve_bc<16>(a, grid, s);
+        if (a.k <= 32) return launch_solve_bc<32>(a, grid, s);
+        return launch_solve_bc<64>(a, grid, s);
+    }
     if (a.k <= 16) hipLaunchKernelGGL((solve_reg_kernel<16>), dim3(grid), dim3(256), 0, s, a);
     else if (a.k <= 32) hipLaunchKernelGGL((solve_reg_kernel<32>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((solve_reg_kernel<64>), dim3(grid), dim3(256), 0, s, a);
@@ -627,29 +1169,55 @@ static int64_t gen_part_doubles(int d, int k) {
     return std::max<int64_t>(4 * (int64_t)d * kp, 64 * (int64_t)d * (k + 1));
 }
 
-size_t generic_workspace_bytes(int d, int k, int64_t n) {
-    const int64_t kp = (int64_t)k * (k + 1) / 2;
-    const int64_t c = std::min<int64_t>(gen_chunk(k), std::max<int64_t>(n, 1));
-    return sizeof(double) * (size_t)((int64_t)d * kp + c * (kp + (k + 1) + 2 + 4) + 64 + gen_part_doubles(d, k));
-}
+static int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 
 struct GenWs {
     double *Q, *G, *Bz, *xx, *mc, *sc, *part;
     int64_t chunk, part_cap;
+    // int8-sliced contractions
+    unsigned char *A, *AT;
+    signed char *BtQ, *BtW;
+    double *scaleQ, *scaleW, *colpart, *rmin;
+    int *flags;
+    int dpad;
+    int64_t npad;
 };
-static GenWs carve(void *ws, int d, int k, int64_t n) {
+static size_t carve_impl(void *ws, int d, int k, int64_t n, GenWs *out) {
     const int64_t kp = (int64_t)k * (k + 1) / 2;
-    GenWs w;
+    GenWs w{};
     w.chunk = std::min<int64_t>(gen_chunk(k), std::max<int64_t>(n, 1));
-    double *p = static_cast<double *>(ws);
-    w.Q = p; p += (int64_t)d * kp;
-    w.G = p; p += w.chunk * kp;
-    w.Bz = p; p += w.chunk * (k + 1);
-    w.xx = p; p += w.chunk;
-    w.mc = p; p += w.chunk;
-    w.sc = p; p += 4 * w.chunk;
-    w.part = p;
+    w.dpad = (int)pad64(d);
+    w.npad = pad64(w.chunk);
     w.part_cap = gen_part_doubles(d, k);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = ws ? static_cast<char *>(ws) + off : nullptr;
+        off += (bytes + 255) / 256 * 256;
+        return p;
+    };
+    w.Q = static_cast<double *>(take(sizeof(double) * (size_t)d * kp));
+    w.G = static_cast<double *>(take(sizeof(double) * (size_t)w.chunk * kp));
+    w.Bz = static_cast<double *>(take(sizeof(double) * (size_t)w.chunk * (k + 1)));
+    w.xx = static_cast<double *>(take(sizeof(double) * (size_t)w.chunk));
+    w.mc = static_cast<double *>(take(sizeof(double) * (size_t)w.chunk));
+    w.sc = static_cast<double *>(take(sizeof(double) * 4 * (size_t)w.chunk));
+    w.part = static_cast<double *>(take(sizeof(double) * (size_t)w.part_cap));
+    w.A = static_cast<unsigned char *>(take((size_t)w.npad * w.dpad));
+    w.AT = static_cast<unsigned char *>(take((size_t)w.dpad * w.npad));
+    w.BtQ = static_cast<signed char *>(take((size_t)GQS * kp * w.dpad));
+    w.BtW = static_cast<signed char *>(take((size_t)GQS * kp * w.npad));
+    w.scaleQ = static_cast<double *>(take(sizeof(double) * (size_t)kp));
+    w.scaleW = static_cast<double *>(take(sizeof(double) * (size_t)kp));
+    w.colpart = static_cast<double *>(take(sizeof(double) * 2 * (size_t)kp * (size_t)((w.chunk + 255) / 256)));
+    w.rmin = static_cast<double *>(take(256));
+    w.flags = static_cast<int *>(take(256));
+    if (out) *out = w;
+    return off;
+}
+size_t generic_workspace_bytes(int d, int k, int64_t n) { return carve_impl(nullptr, d, k, n, nullptr); }
+static GenWs carve(void *ws, int d, int k, int64_t n) {
+    GenWs w;
+    (void)carve_impl(ws, d, k, n, &w);
     return w;
 }
 
@@ -657,6 +1225,7 @@ static GenWs carve(void *ws, int d, int k, int64_t n) {
 __global__ void splitk_reduce_kernel(GemmArgs g, int nslices) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.M * g.N) return;
+    if (g.guard && *g.guard != g.run_if) return;
     const int64_t row = idx / g.N, col = idx - row * g.N;
     double sacc = 0.0;
     for (int z = 0; z < nslices; ++z) sacc += g.part[(int64_t)z * g.M * g.N + idx];
@@ -666,6 +1235,42 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int nslices) {
 
 // part_ws / part_cap: split-K scratch (doubles); a product whose tile grid would not fill the chip ~4x over
 // is cut along K into enough slices to do so.
+static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128));
+    static const int kb = [] {  // 64-byte K-steps (three workgroups per CU); PPCA_I8GEMM_KB=128: whole 128-byte lines, one per CU
+        const char *e = getenv("PPCA_I8GEMM_KB");
+        return (e && atoi(e) == 128) ? 128 : 64;
+    }();
+    if (kb == 64) {
+        const size_t lds = 2 * (128 + GQS * 32) * (64 + 16);
+        hipLaunchKernelGGL((i8gemm_kernel<64>), grid, dim3(256), lds, s, g);
+    } else {
+        const size_t lds = 2 * (128 + GQS * 32) * (128 + 16);
+        static std::atomic<unsigned long long> done{0ull};
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&i8gemm_kernel<128>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            done.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL((i8gemm_kernel<128>), grid, dim3(256), lds, s, g);
+    }
+    return hipGetLastError();
+}
+
+// PPCA_GENERIC_FP64=1: both large contractions on the fp64 MFMA always (A/B runs)
+static bool generic_i8() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_GENERIC_FP64");
+        return !(e && atoi(e) == 1);
+    }();
+    return v;
+}
+
 template <int AMODE>
 static hipError_t launch_gemm(GemmArgs g, hipStream_t s, int n_cu = 256, double *part_ws = nullptr,
                               int64_t part_cap = 0) {
@@ -729,10 +1334,17 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
     GenWs W = carve(ws, d, k, n);
     const double *mean = model + MODEL_HDR + (int64_t)d * k;
     const double *Cm = model + MODEL_HDR;
+    const bool i8 = generic_i8();
     {
         const int64_t tot = (int64_t)d * kp;
         hipLaunchKernelGGL(qtab_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, model, d, k, W.Q);
         GTRY(hipGetLastError());
+        if (i8) {  // digit planes of Q and the Gram guard flag (flags[0]) of this model
+            hipLaunchKernelGGL(gen_rmin_kernel, dim3(1), dim3(256), 0, s, model, d, k, W.rmin, W.flags);
+            hipLaunchKernelGGL(gen_qdigits_kernel, dim3((unsigned)kp), dim3(256), 0, s, model, d, k, W.dpad, (int)kp, W.rmin,
+                               W.scaleQ, W.BtQ, W.flags);
+            GTRY(hipGetLastError());
+        }
     }
     GTRY(set_solve_lds(k));
     if (em) GTRY(hipMemsetAsync(stats, 0, sizeof(double) * (size_t)L.len, s));
@@ -745,10 +1357,24 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         GTRY(hipGetLastError());
         GemmArgs g{};
         g.X = Xc; g.ldx = ldx; g.mean = mean;
-        // G = Mask . Q
+        const int64_t ncpad = pad64(nc);
+        if (i8) {
+            dim3 mg((unsigned)(W.dpad / 64), (unsigned)(ncpad / 64));
+            hipLaunchKernelGGL(gen_maskbytes_kernel, mg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, W.A, W.AT);
+            GTRY(hipGetLastError());
+            // G = Mask . Q on the int8 MFMA (exact integer accumulation) unless the guard raised flags[0]
+            I8GemmArgs q{};
+            q.A = W.A; q.lda = W.dpad; q.Bt = W.BtQ; q.ldb = W.dpad; q.plane = kp * (int64_t)W.dpad;
+            q.M = nc; q.N = kp; q.K = W.dpad; q.scale = W.scaleQ; q.out = W.G; q.ldo = kp; q.accumulate = 0;
+            q.guard = W.flags;
+            GTRY(launch_i8gemm(q, s));
+        }
+        // G = Mask . Q (fp64 MFMA; with the int8 form enabled: only when its guard tripped)
         g.B = W.Q; g.ldb = kp; g.M = nc; g.N = kp; g.K = d;
         g.out0 = W.G; g.ld0 = kp; g.ncols0 = kp; g.out1 = nullptr; g.ld1 = 0; g.accumulate = 0;
+        g.guard = i8 ? W.flags : nullptr; g.run_if = 1;
         GTRY(launch_gemm<0>(g, s));
+        g.guard = nullptr;
         // b = X~ . C
         g.B = Cm; g.ldb = k; g.N = k;
         g.out0 = W.Bz; g.ld0 = k + 1; g.ncols0 = k;
@@ -771,10 +1397,28 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         hipLaunchKernelGGL(scal_reduce_kernel, dim3(1), dim3(256), 0, s, W.sc, wc, nc, scal, (em || r0 > 0) ? 1 : 0);
         GTRY(hipGetLastError());
         if (em) {
-            // S += Mask^T . wP
+            if (i8) {
+                // column scales of wP over the chunk + its guard (flags[1]), digit planes, S += Mask^T . wP on the int8 MFMA
+                const int nb = (int)((nc + 255) / 256);
+                hipLaunchKernelGGL(gen_colstat_kernel, dim3((unsigned)((kp + 255) / 256), (unsigned)nb), dim3(256), 0, s, W.G,
+                                   nc, (int)kp, W.colpart, W.flags);
+                hipLaunchKernelGGL(gen_colscale_kernel, dim3((unsigned)((kp + 255) / 256)), dim3(256), 0, s, W.colpart, nb, nc,
+                                   (int)kp, W.scaleW, W.flags);
+                dim3 dg((unsigned)((kp + 63) / 64), (unsigned)(ncpad / 64));
+                hipLaunchKernelGGL(gen_wdigits_kernel, dg, dim3(256), 0, s, W.G, nc, (int)kp, W.npad, W.scaleW, W.BtW, W.flags);
+                GTRY(hipGetLastError());
+                I8GemmArgs q{};
+                q.A = W.AT; q.lda = W.npad; q.Bt = W.BtW; q.ldb = W.npad; q.plane = kp * W.npad;
+                q.M = d; q.N = kp; q.K = ncpad; q.scale = W.scaleW; q.out = stats + L.S; q.ldo = kp; q.accumulate = 1;
+                q.guard = W.flags + 1;
+                GTRY(launch_i8gemm(q, s));
+            }
+            // S += Mask^T . wP (fp64 MFMA; with the int8 form enabled: only when the chunk's guard tripped)
             g.B = W.G; g.ldb = kp; g.M = d; g.N = kp; g.K = nc;
             g.out0 = stats + L.S; g.ld0 = kp; g.ncols0 = kp; g.accumulate = 1;
+            g.guard = i8 ? W.flags + 1 : nullptr; g.run_if = 1;
             GTRY(launch_gemm<2>(g, s, n_cu, W.part, W.part_cap));
+            g.guard = nullptr;
             // [U | totals] += Mask^T . [wz | w]
             g.B = W.Bz; g.ldb = k + 1; g.N = k + 1;
             g.out0 = stats + L.U; g.ld0 = k; g.ncols0 = k; g.out1 = stats + L.totals; g.ld1 = 1;
