@@ -1,13 +1,12 @@
 mkdir -p gpurun_out/r2t
 export PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_dev.so
-timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "stats_raw or wide_d256" 2>&1 | tail -5
-timeout 300 python bench.py --n 2000000 --steps 10 --warmup 2 --no-cpu > gpurun_out/r2t/dev2m.json 2> gpurun_out/r2t/dev2m.err; tail -2 gpurun_out/r2t/dev2m.err
+timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "stats_raw or wide_d256" 2>&1 | tail -3
 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu > gpurun_out/r2t/dev10m.json 2> gpurun_out/r2t/dev10m.err
-PPCA_EM_ROLES=0 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu > gpurun_out/r2t/dev10m_old.json 2>> gpurun_out/r2t/dev10m.err
 python -c "
 import json
-for f in ('dev2m','dev10m','dev10m_old'):
+for f in ('dev10m',):
     try:
         j=json.load(open('gpurun_out/r2t/%s.json'%f)); print(f, round(j['value'],2), 'it/s', round(j['roofline']['kernel_avg_ms'],3),'ms', 'llk', j['llk_per_sample_last_input_model'])
     except Exception as e: print(f, 'failed', e)
 "
+tail -3 gpurun_out/r2t/dev10m.err
