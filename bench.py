@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # gfx950 correction calibrated on a known byte count): profiles/r01/README.md
 PMC_BYTES_PER_SAMPLE = 2077.5
 FP64_PEAK_TFLOPS = 78.6  # fp64 vector = fp64 matrix spec (dense MFMA peak for f64)
-KERNEL_NAME = "ppca::pass_kernel<10, true, 4, true>"
+KERNEL_NAME = "ppca::pass_kernel<10, true, 4, true, false>"
 
 
 def algorithmic_bytes_per_sample(d: int) -> float:
@@ -95,7 +95,22 @@ def main() -> None:
                          "C-ABI (capi), torch.distributed (torch), or capi with torch as the fallback if the "
                          "communicator cannot be created (auto)")
     ap.add_argument("--dump-model", default=None, help="rank 0 writes the final model to this .npz (tests)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="a BASELINE.json configuration by number (1: toy 10k x 32 x 4 unmasked; 2: 1M x 256 x 10; 3: the "
+                         "headline 10M x 256 x 10 = the default; 4: 2M x 1024 x 64, 50%% block-masked, generic pipeline); "
+                         "0 = take --n/--d/--k/--mask as given")
     args = ap.parse_args()
+    mask_kind, mask_run = 0, 0
+    if args.config == 1:
+        args.n, args.d, args.k, args.mask = 10_000, 32, 4, 0.0
+    elif args.config == 2:
+        args.n, args.d, args.k, args.mask = 1_000_000, 256, 10, 0.3
+    elif args.config == 3:
+        args.n, args.d, args.k, args.mask = 10_000_000, 256, 10, 0.3
+    elif args.config == 4:
+        args.n, args.d, args.k, args.mask = 2_000_000, 1024, 64, 0.5
+        mask_kind, mask_run = 1, 512  # one cyclic run of d/2 masked dims per sample
+        args.cpu_rows = min(args.cpu_rows, 4000)  # (the literal port needs ~3 ms per sample at this shape)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,7 +156,7 @@ def main() -> None:
     mean_true = np.random.default_rng(1012).standard_normal(d)
     truth = P.PPCAModel(0.1, c_true, mean_true)
     a, b = shard_bounds(n, world, rank)
-    spec = _lib.SynthSpec(a, b - a, d, k, 0.1, args.mask, 0, 0, 1013,
+    spec = _lib.SynthSpec(a, b - a, d, k, 0.1, args.mask, mask_kind, mask_run, 1013,
                           truth._c.ctypes.data_as(_lib.c_double_p), truth._mean.ctypes.data_as(_lib.c_double_p))
     import ctypes as C
 
@@ -212,7 +227,17 @@ def main() -> None:
         tflops = flops_launch / t_kernel / 1e12
         gbs = achieved
         fp64_bound = flops_launch / (FP64_PEAK_TFLOPS * 1e12) >= bytes_launch / (HBM_PEAK_GBS * 1e9)
-        traffic = PMC_BYTES_PER_SAMPLE * rows_local if (d, k) == (256, 10) else None
+        traffic, traffic_src = None, None
+        if (d, k) == (256, 10) and mask_kind == 0:
+            # HBM bytes per sample of the dominant kernel by rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950
+            # correction), measured at the headline size and committed with the commit it was measured on
+            try:
+                with open(os.path.join(ROOT, "profiles", "r02", "traffic.json")) as fh:
+                    tj = json.load(fh)
+                traffic = tj["hbm_bytes_per_sample"] * rows_local
+                traffic_src = f"profiles/r02/traffic.json (commit {tj.get('commit')}, N = {tj.get('n_samples')})"
+            except (OSError, KeyError, ValueError):
+                traffic, traffic_src = PMC_BYTES_PER_SAMPLE * rows_local, "profiles/r01/README.md (N = 2 M, round-1 build)"
         roofline = {
             "bound": "mfma" if fp64_bound else "hbm",
             "achieved": tflops if fp64_bound else gbs,
@@ -220,8 +245,10 @@ def main() -> None:
             "unit": "TFLOP/s" if fp64_bound else "GB/s",
             "frac": (tflops / FP64_PEAK_TFLOPS) if fp64_bound else (gbs / HBM_PEAK_GBS),
             "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01/README.md)",
-            "kernel": KERNEL_NAME if (d, k) == (256, 10) else "ppca::pass_kernel / generic pipeline",
+            "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": traffic_src,
+            "kernel": KERNEL_NAME if (d, k) == (256, 10) else ("ppca::pass_kernel<k, true, 4, true>" if _lib.lib().ppca_path_kind(d, k) == 1
+                                                               else "generic split pipeline (all kernels of one pass, timed as one region)"),
             "kernel_avg_ms": kern_avg_ms,
             "kernel_launches": launches,
             "algorithmic_flops_per_launch": flops_launch,
@@ -248,7 +275,8 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"PPCA EM, N={n} samples x d={d}, state_size={k}, {int(100 * args.mask)}% iid masked, "
+            "config": {"workload": f"PPCA EM, N={n} samples x d={d}, state_size={k}, {int(100 * args.mask)}% "
+                                   f"{'block' if mask_kind else 'iid'} masked, "
                                    f"{world} contiguous row shard(s), one all-reduce of {_lib.lib().ppca_stats_len(d, k)} f64 per step",
                        "collective": collective,
                        "n_samples": n, "d": d, "state_size": k, "mask_prob": args.mask, "parallelism": f"dp{world}"},

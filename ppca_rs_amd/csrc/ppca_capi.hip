@@ -479,8 +479,18 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
     if (ppca_path_kind(model->d, model->k) == 0) {
         if (rows) return fail(PPCA_ERR_INVALID, "gathered passes run on the fused path only");
         if (int rc = ensure(ctx->gws, ctx->gws_cap, generic_workspace_bytes(model->d, model->k, ds->n))) return rc;
+        hipEvent_t g0 = nullptr, g1 = nullptr;
+        if (ctx->timing) {  // the whole split pipeline of this pass, as one timed region
+            HIP_TRY(hipEventCreate(&g0));
+            HIP_TRY(hipEventCreate(&g1));
+            HIP_TRY(hipEventRecord(g0, ctx->stream));
+        }
         HIP_TRY(generic_em_accumulate(ds->X, ds->d, ds->w, ds->n, ds->d, model->k, model->p(), stats_dev, ctx->gws->p,
                                       ctx->n_cu, ctx->stream));
+        if (ctx->timing) {
+            HIP_TRY(hipEventRecord(g1, ctx->stream));
+            ctx->events.emplace_back(g0, g1);
+        }
         return PPCA_OK;
     }
     const int grid = fused_grid(n, ctx->n_cu);
