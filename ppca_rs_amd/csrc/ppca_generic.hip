@@ -1017,6 +1017,269 @@ static hipError_t launch_solve_bc(const SolveArgs &a, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------ per-sample solve on the fp64 MFMA (blocked)
+// One wave per sample, M = G + s2 I (padded with an identity block to n = 16 NB) in the wave's LDS area, inverted IN
+// PLACE by the three classical blocked sweeps over 16 x 16 blocks -- every block product is four v_mfma_f64_16x16x4:
+//   potrf   for j: L_jj = chol(A_jj), T_jj = L_jj^-1 (kept in the diagonal block); L_ij = A_ij T_jj^T (i > j);
+//           A_il -= L_ij L_lj^T (j < l <= i)
+//   trtri   W = L^-1: for j descending, i descending: W_ij = -(sum_{t=j+1..i} W_it L_tj) T_jj      (W_ii = T_ii)
+//   lauum   M^-1 = W^T W: for i, for l <= i (l = i last): R_il = sum_{t >= i} W_ti^T W_tl
+// 52 block products at NB = 4 (13 k MFMA cycles) against ~6 k dependent v_readlane / LDS-broadcast multiply-adds per
+// sample of the lane-per-row forms above.  The 16 x 16 diagonal blocks are factored and inverted by the lanes
+// themselves (lane = row, four redundant copies, uniform LDS reads for the shared operands).  Outputs leave through
+// the packed index (coalesced), z = M^-1 b by symmetric row reads.
+template <int NB>
+__global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
+    constexpr int N = 16 * NB, LD = N + 2;
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *Am = gsm + (size_t)wave * (N * LD + 2 * N);
+    double *zs = Am + N * LD;   // z (N)
+    double *bs = zs + N;        // b (N)
+    const int k = a.k, kp = k * (k + 1) / 2;
+    const double s2 = a.model[1], lnsig = a.model[2];
+    auto bcast = [&](double v, int src) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    auto blk = [&](int i, int j) { return Am + (16 * i) * LD + 16 * j; };
+    // D = sign * X' Y' + C with X' = X or X^T, Y' = Y or Y^T (16 x 16 blocks in LDS, leading dimension LD)
+    auto mma = [&](d4g_t acc, const double *X, bool xT, const double *Y, bool yT, double sign) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double av = xT ? X[(4 * s + l4) * LD + l15] : X[l15 * LD + 4 * s + l4];
+            const double bv = yT ? Y[l15 * LD + 4 * s + l4] : Y[(4 * s + l4) * LD + l15];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * av, bv, acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto ldC = [&](const double *Z) {
+        d4g_t v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = Z[(l4 + 4 * r) * LD + l15];
+        return v;
+    };
+    auto stC = [&](double *Z, d4g_t v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[(l4 + 4 * r) * LD + l15] = v[r];
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < a.n; i += stride) {
+        double *g = a.G + i * kp;
+        double *bz = a.Bz + i * (k + 1);
+        // ---- M into LDS, full symmetric, identity padding; b.  The packed Gram is requested in one burst (NPK loads
+        // in flight per lane) before the first LDS store; each lane walks the packed index by 64 (no square roots).
+        constexpr int NPK = (N * (N + 1) / 2 + 63) / 64;
+        double gv[NPK];
+#pragma unroll
+        for (int q = 0; q < NPK; ++q) {
+            const int e = lane + 64 * q;
+            gv[q] = g[e < kp ? e : kp - 1];
+        }
+        if (k < N) {
+            for (int e = lane; e < N * LD; e += 64) Am[e] = 0.0;
+            for (int e = lane; e < N; e += 64)
+                if (e >= k) Am[e * LD + e] = 1.0;
+        }
+        for (int e = lane; e < N; e += 64) bs[e] = (e < k) ? bz[e] : 0.0;
+        {
+            int r = (int)((sqrt(8.0 * (double)lane + 1.0) - 1.0) * 0.5);
+            while ((r + 1) * (r + 2) / 2 <= lane) ++r;
+            while (r * (r + 1) / 2 > lane) --r;
+            int c = lane - r * (r + 1) / 2;
+#pragma unroll
+            for (int q = 0; q < NPK; ++q) {
+                if (lane + 64 * q < kp) {
+                    const double v = gv[q] + (r == c ? s2 : 0.0);
+                    Am[r * LD + c] = v;
+                    Am[c * LD + r] = v;
+                }
+                c += 64;
+                while (c > r) {
+                    c -= r + 1;
+                    ++r;
+                }
+            }
+        }
+        double mant = 1.0;
+        int ex = 0;
+        // ---- potrf
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double *D = blk(j, j);
+            {   // diagonal block: L (lane = row l15), then T = L^-1 (lane = column l15), written back with a zero upper part
+                double row[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) row[c] = D[l15 * LD + c];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const double piv = bcast(row[p], p);
+                    const double rinv = fast_rsqrt(piv);
+                    int e;
+                    mant *= frexp(piv, &e);
+                    ex += e;
+                    row[p] = (l15 == p) ? rinv : row[p] * rinv;
+                    D[l15 * LD + p] = row[p];  // column p of L (diagonal slot: 1 / L_pp); the four copies agree
+#pragma unroll
+                    for (int c = p + 1; c < 16; ++c) row[c] -= row[p] * D[c * LD + p];
+                }
+                double u[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = (r == l15) ? 1.0 : 0.0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    u[t] *= D[t * LD + t];
+#pragma unroll
+                    for (int r = t + 1; r < 16; ++r) u[r] -= D[r * LD + t] * u[t];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) D[r * LD + l15] = (r >= l15) ? u[r] : 0.0;
+            }
+#pragma unroll
+            for (int ii = j + 1; ii < NB; ++ii) {  // L_ij = A_ij T_jj^T
+                d4g_t acc = {0, 0, 0, 0};
+                acc = mma(acc, blk(ii, j), false, D, true, 1.0);
+                stC(blk(ii, j), acc);
+            }
+#pragma unroll
+            for (int ii = j + 1; ii < NB; ++ii)
+#pragma unroll
+                for (int l = j + 1; l <= ii; ++l) {  // A_il -= L_ij L_lj^T
+                    d4g_t acc = ldC(blk(ii, l));
+                    acc = mma(acc, blk(ii, j), false, blk(l, j), true, -1.0);
+                    stC(blk(ii, l), acc);
+                }
+        }
+        const double logdet = log(mant) + (double)ex * LN_2;
+        // ---- trtri: W = L^-1 in place (diagonal blocks already hold T)
+#pragma unroll
+        for (int j = NB - 2; j >= 0; --j)
+#pragma unroll
+            for (int ii = NB - 1; ii > j; --ii) {
+                d4g_t acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = j + 1; t <= ii; ++t) acc = mma(acc, blk(ii, t), false, blk(t, j), false, 1.0);
+                stC(blk(ii, j), acc);  // Y_i (L_ij is no longer needed: rows above use L_tj with t < i only)
+                d4g_t w = {0, 0, 0, 0};
+                w = mma(w, blk(ii, j), false, blk(j, j), false, -1.0);
+                stC(blk(ii, j), w);
+            }
+        // ---- lauum: M^-1 = W^T W, lower blocks, in place
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii)
+#pragma unroll
+            for (int l = 0; l <= ii; ++l) {
+                d4g_t acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = ii; t < NB; ++t) acc = mma(acc, blk(t, ii), true, blk(t, l), false, 1.0);
+                stC(blk(ii, l), acc);
+            }
+        // ---- z = M^-1 b (lane = row; the strict upper part is read through the symmetric entry), traces
+        double zv[N / 64 > 0 ? N / 64 : 1];
+        double quad = 0.0, zz = 0.0, tr = 0.0;
+#pragma unroll
+        for (int q = 0; q < (N + 63) / 64; ++q) {
+            const int r = lane + 64 * q;
+            double zacc = 0.0;
+            if (r < N) {
+                for (int c = 0; c < N; ++c) {
+                    const double mv = (c <= r) ? Am[r * LD + c] : Am[c * LD + r];
+                    zacc += mv * bs[c];
+                }
+                zs[r] = zacc;
+                if (r < k) {
+                    quad += bs[r] * zacc;
+                    zz += zacc * zacc;
+                    tr += Am[r * LD + r];
+                }
+            }
+            zv[q] = zacc;
+        }
+        quad = gwave_sum(quad);
+        zz = gwave_sum(zz);
+        tr = gwave_sum(tr);
+        const double wgt = a.w ? a.w[i] : 1.0;
+        const double xx = a.xx[i];
+        const int m = (int)a.mc[i];
+        const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, k);
+        if (a.em) {
+            // w P = w (z z^T + s2 M^-1), packed, by packed index (coalesced)
+            {
+                int r = (int)((sqrt(8.0 * (double)lane + 1.0) - 1.0) * 0.5);
+                while ((r + 1) * (r + 2) / 2 <= lane) ++r;
+                while (r * (r + 1) / 2 > lane) --r;
+                int c = lane - r * (r + 1) / 2;
+#pragma unroll
+                for (int q = 0; q < NPK; ++q) {
+                    const int e = lane + 64 * q;
+                    if (e < kp) g[e] = wgt * (zs[r] * zs[c] + s2 * Am[r * LD + c]);
+                    c += 64;
+                    while (c > r) {
+                        c -= r + 1;
+                        ++r;
+                    }
+                }
+            }
+            if (lane < k) bz[lane] = wgt * zv[0];
+            if (lane == 0) {
+                bz[k] = wgt;
+                double *sc = a.sc + i * 4;
+                sc[0] = m > 0 ? wgt * s2 * ((double)k - s2 * tr) : 0.0;
+                sc[1] = m > 0 ? wgt * (xx - quad - s2 * zz) : 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = m > 0 ? 1.0 : 0.0;
+            }
+        } else {
+            for (int e = lane; e < kp; e += 64) {
+                int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+                while ((r + 1) * (r + 2) / 2 <= e) ++r;
+                while (r * (r + 1) / 2 > e) --r;
+                const int c = e - r * (r + 1) / 2;
+                g[e] = s2 * Am[r * LD + c];  // Sigma packed, for the covariance diagonals
+            }
+            if (a.covs) {
+                for (int e = lane; e < k * k; e += 64) {
+                    const int r = e / k, c = e - r * k;
+                    a.covs[i * (int64_t)k * k + e] = s2 * (c <= r ? Am[r * LD + c] : Am[c * LD + r]);
+                }
+            }
+            if (lane < k) {
+                bz[lane] = zv[0];
+                if (a.states) a.states[i * k + lane] = zv[0];
+            }
+            if (lane == 0) {
+                double *sc = a.sc + i * 4;
+                sc[0] = 0.0;
+                sc[1] = 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = 0.0;
+                if (a.llks) a.llks[i] = lk;
+            }
+        }
+    }
+}
+
+template <int NB>
+static hipError_t launch_solve_mfma(const SolveArgs &a, int grid, hipStream_t s) {
+    constexpr int N = 16 * NB, LD = N + 2;
+    const size_t lds = sizeof(double) * 4 * (N * LD + 2 * N);
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (lds > 65536 && !(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_mfma_kernel<NB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((solve_mfma_kernel<NB>), dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
     int grid = (int)std::min<int64_t>((a.n + 3) / 4, (int64_t)n_cu);
     if (grid < 1) grid = 1;
@@ -1024,6 +1287,16 @@ static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
         const char *e = getenv("PPCA_GENERIC_REG_SOLVE");
         return e && atoi(e) == 1;
     }();
+    static const int form = [] {  // PPCA_GENERIC_SOLVE = mfma (default) | bc (LDS-broadcast, lane per row)
+        const char *e = getenv("PPCA_GENERIC_SOLVE");
+        return (e && e[0] == 'b') ? 1 : 0;
+    }();
+    if (!reg && form == 0) {
+        if (a.k <= 16) return launch_solve_mfma<1>(a, grid, s);
+        if (a.k <= 32) return launch_solve_mfma<2>(a, grid, s);
+        if (a.k <= 48) return launch_solve_mfma<3>(a, grid, s);
+        return launch_solve_mfma<4>(a, grid, s);
+    }
     if (!reg) {
         if (a.k <= 16) return launch_solve_bc<16>(a, grid, s);
         if (a.k <= 32) return launch_solve_bc<32>(a, grid, s);
