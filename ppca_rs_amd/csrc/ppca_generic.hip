@@ -414,7 +414,7 @@ struct I8GemmArgs {
 
 // KB = bytes of K per staged step (64 or 128: whole 128-byte lines per row at 128); rows padded by 16 B in LDS.
 template <int KB>
-__global__ __launch_bounds__(256) void i8gemm_kernel(I8GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two waves per SIMD (<= 256 registers): measured 64 vs 76 ms per iteration at 1 wave, 118 ms at 3 (spills)
     constexpr int RS = KB + 16, PR = KB / 16;           // LDS row stride, 16-byte pieces per row
     constexpr int NA = 128 * PR / 256, NB = GQS * 32 * PR / 256;  // pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char i8sm[];
