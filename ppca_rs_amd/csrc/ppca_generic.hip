@@ -225,27 +225,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 constexpr int GQS = 8;
 typedef int gi4_t __attribute__((ext_vector_type(4)));
 
-// mask bytes of a chunk in both orientations: A[i][dpad] (row = sample) and AT[j][npad] (row = dim), zero padded
+// mask bytes of a chunk in both orientations: A[i][dpad] (row = sample) and AT[j][npad] (row = dim), zero padded.
+// 64 samples x 64 dims per workgroup: every wave reads 16 rows as whole 512-byte segments (lane = dim), each lane
+// drops its flag byte into an LDS tile, and the tile leaves as 16-byte pieces in both orientations.
 __global__ __launch_bounds__(256) void gen_maskbytes_kernel(const double *X, int64_t ldx, int64_t n, int d, int dpad,
                                                             int64_t npad, unsigned char *A, unsigned char *AT) {
-    __shared__ unsigned char tile[64][80];
-    const int t = threadIdx.x, r = t >> 2, q = t & 3;
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64][80];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t i0 = (int64_t)blockIdx.y * 64;
     const int j0 = blockIdx.x * 64;
-    const int64_t row = i0 + r;
-    union { unsigned char b[16]; gi4_t v; } u;
+    const int j = j0 + lane;
+    double v[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int j = j0 + 16 * q + e;
-        u.b[e] = (row < n && j < d && __builtin_isfinite(X[row * ldx + j])) ? 1 : 0;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int64_t row = i0 + 16 * wave + rr;
+        v[rr] = (row < n && j < d) ? X[row * ldx + j] : __builtin_nan("");
     }
-    if (row < npad) *reinterpret_cast<gi4_t *>(A + row * dpad + j0 + 16 * q) = u.v;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) tile[r][16 * q + e] = u.b[e];
+    for (int rr = 0; rr < 16; ++rr) tile[16 * wave + rr][lane] = __builtin_isfinite(v[rr]) ? 1 : 0;
     __syncthreads();
+    const int r = t >> 2, q = t & 3;
+    union { unsigned char b[16]; gi4_t vv; } u;
+    u.vv = *reinterpret_cast<const gi4_t *>(&tile[r][16 * q]);
+    *reinterpret_cast<gi4_t *>(A + (i0 + r) * dpad + j0 + 16 * q) = u.vv;  // rows up to npad: zeros beyond n
 #pragma unroll
     for (int e = 0; e < 16; ++e) u.b[e] = tile[16 * q + e][r];
-    *reinterpret_cast<gi4_t *>(AT + (int64_t)(j0 + r) * npad + i0 + 16 * q) = u.v;  // dims up to dpad: zeros
+    *reinterpret_cast<gi4_t *>(AT + (int64_t)(j0 + r) * npad + i0 + 16 * q) = u.vv;  // dims up to dpad: zeros beyond d
 }
 
 // smallest non-zero squared row norm of C (guard of the Gram digits); one workgroup
