@@ -358,45 +358,35 @@ __global__ __launch_bounds__(256) void gen_colscale_kernel(const double *part, i
     // finite, and the maximum within 2^20 of the mean magnitude
     if (!(sm < 1.0e300) || !(mx * (double)n <= 1048576.0 * sm)) atomicOr(&flags[1], 1);
 }
-// digits of V[n][kp] (row-major) -> planes BtW[s][c][npad] (samples contiguous): 64 samples x 64 columns per workgroup
+// digits of V[n][kp] (row-major) -> planes BtW[s][c][npad] (samples contiguous): 64 samples x 64 columns per
+// workgroup, lane = column (rows read as whole 512-byte segments), wave w = samples 16 w .. 16 w + 15 -- the 16 digits
+// of one (slice, column) are 16 consecutive bytes of the output: one 16-byte store, no transposition
 __global__ __launch_bounds__(256) void gen_wdigits_kernel(const double *V, int64_t n, int kp, int64_t npad, const double *scale,
                                                           signed char *BtW, const int *flags) {
-    __shared__ signed char tile[GQS][64][80];
     if (flags[1]) return;
-    const int t = threadIdx.x, r = t >> 2, q = t & 3;
-    const int64_t i0 = (int64_t)blockIdx.y * 64;
-    const int c0 = blockIdx.x * 64;
-    const int64_t row = i0 + r;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t i0 = (int64_t)blockIdx.y * 64 + 16 * wave;
+    const int c = blockIdx.x * 64 + lane;
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = (i0 + e < n && c < kp) ? V[(i0 + e) * kp + c] : 0.0;
+    if (c >= kp) return;
+    int ex;
+    (void)frexp(scale[c], &ex);  // scale = 2^(ex - 1)
+    const int shift = -(ex - 1);
+    union { signed char b[GQS][16]; gi4_t q[GQS]; } u;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int c = c0 + 16 * q + e;
-        double v = 0.0;
-        int shift = 0;
-        if (row < n && c < kp) {
-            v = V[row * kp + c];
-            int ex;
-            (void)frexp(scale[c], &ex);  // scale = 2^(ex - 1)
-            shift = -(ex - 1);
-        }
-        long long I = llrint(ldexp(v, shift));
+        long long I = llrint(ldexp(v[e], shift));
 #pragma unroll
         for (int sl = 0; sl < GQS; ++sl) {
             const int dig = (int)((I + 64) & 127) - 64;
             I = (I - dig) >> 7;
-            tile[sl][16 * q + e][r] = (signed char)dig;
+            u.b[sl][e] = (signed char)dig;
         }
     }
-    __syncthreads();
-    // 8 slices x 64 columns x 4 pieces of 16 samples
-    for (int idx = t; idx < GQS * 64 * 4; idx += 256) {
-        const int piece = idx & 3, cc = (idx >> 2) & 63, sl = idx >> 8;
-        const int c = c0 + cc;
-        if (c >= kp) continue;
-        union { signed char b[16]; gi4_t v; } u;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) u.b[e] = tile[sl][cc][16 * piece + e];
-        *reinterpret_cast<gi4_t *>(BtW + ((int64_t)sl * kp + c) * npad + i0 + 16 * piece) = u.v;
-    }
+    for (int sl = 0; sl < GQS; ++sl) *reinterpret_cast<gi4_t *>(BtW + ((int64_t)sl * kp + c) * npad + i0) = u.q[sl];
 }
 
 // C[M x N] (+)= scale[c] * sum_s 128^s ( A[M x K] . Bt[s][N x K]^T ), bytes, K a multiple of 64.
