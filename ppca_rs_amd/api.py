@@ -358,9 +358,15 @@ class PPCAModel:
     def init(state_size: int, dataset: Dataset, seed: Optional[int] = None) -> "PPCAModel":
         """Random untrained model (ppca_model.rs:51-70): C ~ N(0,1) with the rows of
         all-masked dimensions zeroed, sigma = 1, mean = 0.  `seed` is an extension
-        (the reference's RNG cannot be seeded)."""
+        (the reference's RNG cannot be seeded).
+
+        LIMIT: state_size <= 64.  The reference takes any state size; here the per-sample k x k inversion is one
+        wave's job (a 64 x 64 matrix in 33 KB of LDS, ppca_generic.hip::solve_mfma_kernel) and the M-step row solves
+        keep one row per lane.  Larger state sizes raise here instead of at the first kernel launch."""
         if len(dataset) == 0:
             raise ValueError("dataset is empty")  # assert!(!dataset.is_empty()) :52
+        if state_size > 64:
+            raise ValueError(f"state_size {state_size} is not supported: the MI355X kernels cover state sizes up to 64")
         d = dataset.output_size()
         rng = np.random.default_rng(seed)
         # DMatrix::from_vec is column-major (utils.rs:16-25)

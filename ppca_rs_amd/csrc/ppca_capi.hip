@@ -622,7 +622,8 @@ extern "C" int ppca_em_finalize_host(int32_t d, int32_t k, double sigma, const d
     const double tau = prior ? prior->transformation_precision : 0.0;
     double totsum = 0.0;
     for (int j = 0; j < d; ++j) totsum += stats[L.totals + j];
-    const double sq = stats[L.scalars + SC_SQERR], dv = stats[L.scalars + SC_DEVSQ];
+    // (clamp: see finalize_kernel, ppca_kernels.hip)
+    const double sq = stats[L.scalars + SC_SQERR], dv = std::max(stats[L.scalars + SC_DEVSQ], -stats[L.scalars + SC_SQERR]);
     const double s2new = (prior && prior->has_isotropic_noise_prior)
                              ? ((sq + dv) / 2.0 + prior->isotropic_noise_beta) /
                                    (totsum / 2.0 + prior->isotropic_noise_alpha + 1.0)

@@ -1402,7 +1402,8 @@ __global__ void gen_finalize_misc_kernel(const double *stats, const double *min,
         __syncthreads();
     }
     const double totsum = red[0];
-    const double sq = stats[L.scalars + SC_SQERR], dv = stats[L.scalars + SC_DEVSQ];
+    // (clamp: see finalize_kernel, ppca_kernels.hip)
+    const double sq = stats[L.scalars + SC_SQERR], dv = fmax(stats[L.scalars + SC_DEVSQ], -stats[L.scalars + SC_SQERR]);
     const double s2new = has_ig ? ((sq + dv) / 2.0 + beta) / (totsum / 2.0 + alpha + 1.0) : (sq + dv) / totsum;
     const double *Cold = min + MODEL_HDR;
     const double *Mold = Cold + (int64_t)d * k;

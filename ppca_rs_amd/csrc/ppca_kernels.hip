@@ -1091,7 +1091,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *stats, cons
         __syncthreads();
     }
     const double totsum = red[0];
-    const double sq = stats[L.scalars + SC_SQERR], dv = stats[L.scalars + SC_DEVSQ];
+    // deviations_square_sum comes from the identity |x~ - C z|^2 = |x~|^2 - b^T z - s2 |z|^2 (one pass): when the
+    // residual is ~1e-16 of |x~|^2 (noise-free low-rank data) the difference can round below zero where the reference's
+    // explicitly formed residual (ppca_model.rs:337-346) cannot; a negative total is clamped to 0 (sigma = 0), never NaN
+    const double sq = stats[L.scalars + SC_SQERR], dv = fmax(stats[L.scalars + SC_DEVSQ], -stats[L.scalars + SC_SQERR]);
     const double s2new = has_ig ? ((sq + dv) / 2.0 + beta) / (totsum / 2.0 + alpha + 1.0) : (sq + dv) / totsum;
     const double *Cold = min + MODEL_HDR;
     const double *Mold = Cold + (int64_t)d * K;

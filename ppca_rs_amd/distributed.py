@@ -273,8 +273,9 @@ class ShardedMixEM:
     all-reduce(SUM) of [K statistic buffers | K weight sums | llk]; identical finalisation and new log-weights
     (:335) on every rank.  `backend` supplies the per-shard pieces (default: this rank's GPU through the C-ABI)."""
 
-    def __init__(self, shard, start, prior: Optional[Prior] = None, group=None, backend=None):
+    def __init__(self, shard, start, prior: Optional[Prior] = None, group=None, backend=None, comm=None):
         self.group = group
+        self.comm = comm  # a Communicator: both all-reduces run inside the library (ppca_comm_allreduce, RCCL)
         self.log_weights = np.array(start.log_weights, dtype=np.float64)
         self.nm = len(start.models)
         self.backend = backend or _DeviceMixBackend(shard, start.models, prior)
@@ -287,7 +288,11 @@ class ShardedMixEM:
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         llk_local = be.responsibilities(self.log_weights)
         mx = be.max_tensor([be.local_max(c) for c in range(nm)])
-        if multi:
+        if self.comm is not None:
+            be.torch.cuda.current_stream().synchronize()  # mx was filled on torch's stream, the collective runs on the library's
+            self.comm.allreduce(mx.data_ptr(), nm, "max")
+            self.comm.ctx.synchronize()
+        elif multi:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
         mx = np.asarray(mx.cpu().numpy(), dtype=np.float64)
         shifts = np.where(np.isfinite(mx), mx, 0.0)
@@ -295,7 +300,11 @@ class ShardedMixEM:
         for c in range(nm):
             sums[c], _ = be.accumulate(c, float(shifts[c]))
         packed = be.pack(np.concatenate([sums, [llk_local]]))
-        if multi:
+        if self.comm is not None:
+            be.torch.cuda.current_stream().synchronize()
+            self.comm.allreduce(packed.data_ptr(), packed.numel(), "sum")
+            self.comm.ctx.synchronize()
+        elif multi:
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
         extras = be.unpack_extras(packed, nm + 1)
         for c in range(nm):

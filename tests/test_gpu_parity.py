@@ -751,6 +751,23 @@ def test_library_rccl_communicator_single_rank(P, oracle):
         comm.allreduce(u.data_ptr(), u.numel(), op)
         ctx.synchronize()
         assert torch.equal(u, t)
+    # the sharded mixture step with both of its all-reduces (MAX of the component maxima, SUM of the statistics) inside
+    # the library: a clique of one must reproduce PPCAMix.iterate
+    from ppca_rs_amd.distributed import ShardedMixEM
+
+    xm = np.concatenate([oracle.synth(400, 24, 3, 0.25, 300 + c_, mean_scale=3.0)[0] for c_ in range(3)])
+    mrng = np.random.default_rng(9)
+    mix0 = P.PPCAMix([P.PPCAModel(1.0, mrng.standard_normal((24, 3)), mrng.standard_normal(24)) for _ in range(3)],
+                     np.log([0.3, 0.3, 0.4]))
+    dsm = P.Dataset(xm, mrng.uniform(0.5, 1.5, xm.shape[0]))
+    want_mix, want_mllk = mix0.iterate_with_llk(dsm)
+    sm = ShardedMixEM(dsm, mix0, comm=comm)
+    got_mllk = sm.step()
+    got_mix = sm.mixture()
+    assert abs(got_mllk - want_mllk) < 1e-12 * abs(want_mllk)
+    assert _rel(got_mix.log_weights, want_mix.log_weights) < 1e-12
+    for ga, wa in zip(got_mix.models, want_mix.models):
+        assert _rel(ga.transform, wa.transform) < 1e-12 and abs(ga.isotropic_noise - wa.isotropic_noise) < 1e-13
     # one thread, a group of one device
     lib = _lib.lib()
     comms = (C.c_void_p * 1)()
