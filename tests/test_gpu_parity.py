@@ -575,17 +575,20 @@ def test_two_ranks_on_one_gpu_match_single_rank(P, tmp_path):
     assert abs(a["llk"] - b["llk"]) < 1e-10 * abs(a["llk"])
 
 
-def test_sharded_mixture_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("shape", ["small", "cfg5"])
+def test_sharded_mixture_two_ranks_on_one_gpu(shape):
     """BASELINE config 5's multi-GPU path (ShardedMixEM: all-reduce MAX of the component maxima, one all-reduce SUM
     of K statistic buffers + weight sums + llk) with two gloo ranks sharing this GPU, against the single-process
-    PPCAMix.iterate on the whole dataset."""
+    PPCAMix.iterate on the whole dataset -- at a small shape and at config 5's own (8 components, d = 256, k = 10,
+    weighted; there also against the committed oracle fixture)."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "tools", "mix_sharded_check.py")],
+                        "--master-addr", "127.0.0.1", "--master-port", "29541" if shape == "small" else "29543",
+                        os.path.join(root, "tools", "mix_sharded_check.py")] + ([] if shape == "small" else ["cfg5"]),
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "sharded mixture OK" in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])
 
