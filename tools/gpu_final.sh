@@ -17,5 +17,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mix -- python3 $
 cd $GRAFT_REPO_ROOT
 python bench.py --config 4 --steps 5 --warmup 1 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
 python tools/time_mix.py 5000000 256 10 8 16 > $OUT/mix_cfg5.log 2>&1
-python tools/time_passes.py > $OUT/passes.log 2>&1
+python tools/time_passes.py 4000000 256 10 > $OUT/passes.log 2>&1
 ls -la $OUT
