@@ -887,3 +887,71 @@ def test_mixture_with_different_state_sizes(P):
         assert _rel(mix.log_weights, lw1) < 1e-8
         sig, cs, ms, lw = list(s1), c1, m1, lw1
     assert mix.smooth(ds).numpy().shape == x.shape and mix.infer(ds).posteriors().shape == (n, 3)
+
+
+def test_full_size_properties_config4(P):
+    """BASELINE config 4 at full size (N = 2M, d = 1024, k = 64, one cyclic run of d/2 masked dims per sample; the
+    generic pipeline with both int8-sliced contractions and the MFMA-blocked inversion): size-independent properties
+    -- EM monotonicity, shard additivity of the statistics, run-to-run bit reproducibility, extrapolate keeps observed
+    entries -- and the int8 engine against the fp64 GEMMs on a slice (PPCA_GENERIC_FP64 is read once per process, so
+    the comparison is between the shard sums and a finer sharding, which take different chunkings)."""
+    from ppca_rs_amd import _lib
+
+    n, d, k = 2_000_000, 1024, 64
+    ctx = _lib.default_context()
+    truth = P.PPCAModel(0.1, np.random.default_rng(1).standard_normal((d, k)), np.random.default_rng(2).standard_normal(d))
+    spec = _lib.SynthSpec(0, n, d, k, 0.1, 0.0, 1, d // 2, 1033, truth._c.ctypes.data_as(_lib.c_double_p),
+                          truth._mean.ctypes.data_as(_lib.c_double_p))
+    h = C.c_void_p()
+    _lib.check(_lib.lib().ppca_dataset_generate(ctx.handle, C.byref(spec), C.byref(h)))
+    ds = P.Dataset._wrap(h, ctx)
+    m = P.PPCAModel.init(k, ds, seed=3)
+    prev = -np.inf
+    for _ in range(3):
+        m, llk = m.iterate_with_llk(ds)
+        assert np.isfinite(llk) and llk >= prev
+        prev = llk
+    sub = ds._slice(0, 300_000)
+    L = _lib.lib().ppca_stats_len(d, k)
+    dev = m._device(ctx)
+    full, again, acc = np.empty(L), np.empty(L), np.zeros(L)
+    _lib.check(_lib.lib().ppca_stats_raw(ctx.handle, sub._h, dev.h, _lib.ptr(full)))
+    _lib.check(_lib.lib().ppca_stats_raw(ctx.handle, sub._h, dev.h, _lib.ptr(again)))
+    np.testing.assert_array_equal(full, again)
+    for ch in sub.chunks(8):
+        part = np.empty(L)
+        _lib.check(_lib.lib().ppca_stats_raw(ctx.handle, ch._h, dev.h, _lib.ptr(part)))
+        acc += part
+    assert _rel(acc, full) < 1e-10
+    x = ds._slice(0, 512).numpy()
+    assert abs(np.isnan(x).mean() - 0.5) < 0.01  # half of every row masked
+    ex = m.extrapolate(ds._slice(0, 512)).numpy()
+    ob = np.isfinite(x)
+    np.testing.assert_array_equal(ex[ob], x[ob])
+    assert np.isfinite(ex).all()
+
+
+def test_full_size_properties_config5(P):
+    """BASELINE config 5 at full size on one GPU (8 components, N = 5M, d = 256, k = 10, 30 % masked): the mixture
+    log-likelihood never decreases over EM iterations (mix.rs:281-337 is an EM step), the weights stay normalised,
+    and the step is reproducible bit for bit (deterministic row selection and reductions)."""
+    n, d, k, nm = 5_000_000, 256, 10, 8
+    rng = np.random.default_rng(1)
+    parts = [P.PPCAModel(0.1, rng.standard_normal((d, k)), 3.0 * rng.standard_normal(d)).sample(n // nm, 0.3, seed=100 + c)
+             for c in range(nm)]
+    ds = P.Dataset.concat(parts)
+    del parts
+    mix = P.PPCAMix.init(nm, k, ds, seed=7)
+    prev = -np.inf
+    for it in range(6):
+        new, llk = mix.iterate_with_llk(ds)
+        assert np.isfinite(llk) and llk >= prev - 1e-9 * abs(llk), it
+        prev = llk
+        if it == 4:
+            again, llk2 = mix.iterate_with_llk(ds)
+            assert llk2 == llk
+            for a, b in zip(new.models, again.models):
+                np.testing.assert_array_equal(a.transform, b.transform)
+            np.testing.assert_array_equal(new.log_weights, again.log_weights)
+        mix = new
+        assert abs(np.exp(mix.log_weights).sum() - 1.0) < 1e-12
