@@ -61,6 +61,9 @@ hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);
 // The EM pass as an 8-wave workgroup with front / accumulator roles (ppca_em_roles.hip); honours a.qflag like the
 // int8 instantiation of pass_kernel (returns at once when the guard selects the fp64 Gram).
 hipError_t launch_em_roles(int k, int grid, const PassArgs &a, hipStream_t s);
+// The log-likelihood sweep alone (ppca_llk.hip): per-sample llks (nullable) and the per-workgroup scalars; honours
+// a.qflag like the int8 instantiation of pass_kernel.
+hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s);
 hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s);
 hipError_t launch_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
                            int has_ig, double alpha, double beta, hipStream_t s);

@@ -1381,6 +1381,14 @@ static int gram_mode() {
     return v;
 }
 
+static bool llk2_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_LLK2");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+
 // PPCA_EM_ROLES=1 selects the role-split 8-wave EM kernel (ppca_em_roles.hip): bit-identical statistics, measured
 // 71.2 vs 71.8 EM it/s at N = 10 M -- kept as a measured alternative, see the note at the top of that file.
 static bool em_roles() {
@@ -1409,6 +1417,9 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
     const bool roles = EM && em_roles() && !a.rows;
     auto int8_pass = [&](const PassArgs &b) {
         if (roles) return launch_em_roles(K, grid, b, s);
+        if constexpr (!EM) {  // llk / llks alone: the two-tile sweep (ppca_llk.hip) unless PPCA_LLK2=0
+            if (!b.states && !b.covs && !b.recon && llk2_enabled()) return launch_llk2(K, grid, b, s);
+        }
         if constexpr (EM) {
             if (b.rows) return launch_pass_t<K, EM, 4, true, true>(grid, b, s);
         }

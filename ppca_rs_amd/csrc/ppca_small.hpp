@@ -136,6 +136,23 @@ struct Posterior {
         sched_fence();
     }
 
+    // quad = b^T M^-1 b = |L^-1 b|^2 alone (the log-likelihood needs no z): the forward substitution of solve()
+    template <class BLoad>
+    PPCA_HD double forward_quad(BLoad bload) const {
+        double y[K];
+#pragma unroll
+        for (int a = 0; a < K; ++a) y[a] = bload(a);
+        double quad = 0.0;
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            y[t] *= L[tri(t, t)];
+            quad += y[t] * y[t];
+#pragma unroll
+            for (int a = t + 1; a < K; ++a) y[a] -= L[tri(a, t)] * y[t];
+        }
+        return quad;
+    }
+
     template <class Store>
     PPCA_HD double minv_column(int c, Store st) const {
         double u[K];
