@@ -1381,6 +1381,14 @@ static int gram_mode() {
     return v;
 }
 
+static bool em2_enabled() {  // PPCA_EM2=1: the two-tile EM kernel (ppca_em2.hip)
+    static const bool v = [] {
+        const char *e = getenv("PPCA_EM2");
+        return e && atoi(e) == 1;
+    }();
+    return v;
+}
+
 static bool llk2_enabled() {
     static const bool v = [] {
         const char *e = getenv("PPCA_LLK2");
@@ -1417,6 +1425,9 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
     const bool roles = EM && em_roles() && !a.rows;
     auto int8_pass = [&](const PassArgs &b) {
         if (roles) return launch_em_roles(K, grid, b, s);
+        if constexpr (EM && K >= 2) {
+            if (!b.rows && em2_enabled()) return launch_em2(K, grid, b, s);
+        }
         if constexpr (!EM) {  // llk / llks alone: the two-tile sweep (ppca_llk.hip) unless PPCA_LLK2=0
             if (!b.states && !b.covs && !b.recon && llk2_enabled()) return launch_llk2(K, grid, b, s);
         }

@@ -87,11 +87,20 @@ struct Posterior {
     // ran at ~12 cycles per operation on one wave per SIMD instead of the ~6 the fp64 pipe issues at.
     template <class GLoad>
     PPCA_HD void factor(GLoad gload, double s2, double &pm, int &pe) {
-        double grp[2] = {1.0, 1.0};
+        load(gload, s2);
+        factor_loaded(pm, pe);
+    }
+    // factor() in two steps, for callers that must synchronise between reading G and the rest (the Gram is
+    // overwritten in place by the results): M = G + s2 I into the registers, then the factorisation proper
+    template <class GLoad>
+    PPCA_HD void load(GLoad gload, double s2) {
 #pragma unroll
         for (int e = 0; e < KP; ++e) L[e] = gload(e);
 #pragma unroll
         for (int a = 0; a < K; ++a) L[tri(a, a)] += s2;
+    }
+    PPCA_HD void factor_loaded(double &pm, int &pe) {
+        double grp[2] = {1.0, 1.0};
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const double piv = L[tri(c, c)];
@@ -117,6 +126,10 @@ struct Posterior {
     PPCA_HD void solve(BLoad bload, double (&z)[K], double &quad, double &zz) const {
 #pragma unroll
         for (int a = 0; a < K; ++a) z[a] = bload(a);
+        solve_loaded(z, quad, zz);
+    }
+    // the same with b already in z
+    PPCA_HD void solve_loaded(double (&z)[K], double &quad, double &zz) const {
         quad = 0.0;
 #pragma unroll
         for (int t = 0; t < K; ++t) {
