@@ -405,6 +405,11 @@ struct I8GemmArgs {
     int64_t ldo;
     int accumulate;
     const int *guard;  // run only if *guard == 0
+    // split-K in two (blockIdx.z): half 0 covers [0, ksplit) and goes to `out`, half 1 covers [ksplit, K) and goes to the
+    // dense M x N buffer `out2` (overwritten), which add_partial_kernel then adds to `out` -- a fixed order.  Used
+    // where the tile grid is a few workgroups more than the chip holds at once (S: 520 tiles on 512 slots).
+    int64_t ksplit;    // 0 = no split
+    double *out2;
 };
 
 // KB = bytes of K per staged step (64 or 128: whole 128-byte lines per row at 128); rows padded by 16 B in LDS.
@@ -422,6 +427,8 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
     //  side -- measured SLOWER, 106 vs 97 ms per iteration at N = 400 k, d = 1024, k = 64: plain 2-D order kept)
     const int64_t m0 = (int64_t)blockIdx.y * 128;
     const int64_t n0 = (int64_t)blockIdx.x * 32;
+    const bool second = g.ksplit > 0 && blockIdx.z == 1;
+    const int64_t kbeg = second ? g.ksplit : 0, kend = (g.ksplit > 0 && !second) ? g.ksplit : g.K;
     gi4_t acc[2][2][GQS];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -435,14 +442,14 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
         for (int u = 0; u < NA; ++u) {
             const int piece = tid + 256 * u, r = piece / PR, q = piece % PR;
             const int64_t row = m0 + r;
-            ra[u] = (row < g.M && k0 + 16 * q < g.K) ? *reinterpret_cast<const gi4_t *>(g.A + row * g.lda + k0 + 16 * q)
+            ra[u] = (row < g.M && k0 + 16 * q < kend) ? *reinterpret_cast<const gi4_t *>(g.A + row * g.lda + k0 + 16 * q)
                                                      : gi4_t{0, 0, 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int piece = tid + 256 * u, q = piece % PR, rr = piece / PR, cc = rr & 31, sl = rr >> 5;
             const int64_t col = n0 + cc;
-            rb[u] = (col < g.N && k0 + 16 * q < g.K)
+            rb[u] = (col < g.N && k0 + 16 * q < kend)
                         ? *reinterpret_cast<const gi4_t *>(g.Bt + sl * g.plane + col * g.ldb + k0 + 16 * q)
                         : gi4_t{0, 0, 0, 0};
         }
@@ -459,12 +466,12 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
             *reinterpret_cast<gi4_t *>(Bs + (buf * GQS * 32 + piece / PR) * RS + 16 * (piece % PR)) = rb[u];
         }
     };
-    fetch(0);
+    fetch(kbeg);
     stash(0);
     __syncthreads();
     int buf = 0;
-    for (int64_t k0 = 0; k0 < g.K; k0 += KB) {
-        const bool more = k0 + KB < g.K;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += KB) {
+        const bool more = k0 + KB < kend;
         if (more) fetch(k0 + KB);
 #pragma unroll
         for (int h = 0; h < KB / 64; ++h) {
@@ -501,8 +508,12 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
                 double v = (double)acc[a][b][GQS - 1][r];
 #pragma unroll
                 for (int s = GQS - 2; s >= 0; --s) v = v * 128.0 + (double)acc[a][b][s][r];
-                double *dst = g.out + row * g.ldo + col;
-                *dst = g.accumulate ? *dst + v * sc : v * sc;
+                if (second) {
+                    g.out2[row * g.N + col] = v * sc;
+                } else {
+                    double *dst = g.out + row * g.ldo + col;
+                    *dst = g.accumulate ? *dst + v * sc : v * sc;
+                }
             }
     }
 }
@@ -1504,9 +1515,18 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int nslices) {
 
 // part_ws / part_cap: split-K scratch (doubles); a product whose tile grid would not fill the chip ~4x over
 // is cut along K into enough slices to do so.
+// out[r][c] += part[r][c] (the second K-half of a split int8 contraction)
+__global__ void add_partial_kernel(double *out, int64_t ldo, const double *part, int64_t M, int64_t N, const int *guard) {
+    if (guard && *guard != 0) return;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const int64_t r = idx / N, c = idx - r * N;
+    out[r * ldo + c] += part[idx];
+}
+
 static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128));
+    dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128), g.ksplit > 0 ? 2u : 1u);
     static const int kb = [] {  // 64-byte K-steps (three workgroups per CU); PPCA_I8GEMM_KB=128: whole 128-byte lines, one per CU
         const char *e = getenv("PPCA_I8GEMM_KB");
         return (e && atoi(e) == 128) ? 128 : 64;
@@ -1527,6 +1547,11 @@ static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
             done.fetch_or(bit, std::memory_order_release);
         }
         hipLaunchKernelGGL((i8gemm_kernel<128>), grid, dim3(256), lds, s, g);
+    }
+    if (g.ksplit > 0) {
+        const int64_t tot = g.M * g.N;
+        hipLaunchKernelGGL(add_partial_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, g.out, g.ldo, g.out2, g.M, g.N,
+                           g.guard);
     }
     return hipGetLastError();
 }
@@ -1680,6 +1705,13 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
                 q.A = W.AT; q.lda = W.npad; q.Bt = W.BtW; q.ldb = W.npad; q.plane = kp * W.npad;
                 q.M = d; q.N = kp; q.K = ncpad; q.scale = W.scaleW; q.out = stats + L.S; q.ldo = kp; q.accumulate = 1;
                 q.guard = W.flags + 1;
+                {   // two workgroups fit a CU: a grid a little above that many tiles runs a nearly empty second round
+                    const int64_t tiles = ((q.M + 127) / 128) * ((q.N + 31) / 32), slots = 2 * (int64_t)n_cu;
+                    if (tiles > slots && tiles < slots + slots / 2 && q.M * q.N <= W.part_cap && ncpad >= 256) {
+                        q.ksplit = (ncpad / 2 + 63) / 64 * 64;
+                        q.out2 = W.part;
+                    }
+                }
                 GTRY(launch_i8gemm(q, s));
             }
             // S += Mask^T . wP (fp64 MFMA; with the int8 form enabled: only when the chunk's guard tripped)
