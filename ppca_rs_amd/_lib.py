@@ -64,6 +64,7 @@ SIGNATURES = {
     "ppca_ctx_destroy": (C.c_int, [C.c_void_p]),
     "ppca_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ppca_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "ppca_ctx_trim": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ppca_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "ppca_ctx_kernel_time": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_int64), C.c_int32]),
     "ppca_dataset_from_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, c_void_pp]),
@@ -199,6 +200,12 @@ class Context:
 
     def synchronize(self) -> None:
         check(lib().ppca_ctx_synchronize(self.handle))
+
+    def trim(self) -> int:
+        """Returns the device blocks the context keeps for reuse to the device; the number of bytes released."""
+        got = C.c_int64(0)
+        check(lib().ppca_ctx_trim(self.handle, C.byref(got)))
+        return int(got.value)
 
     def enable_timing(self, on: bool) -> None:
         check(lib().ppca_ctx_enable_timing(self.handle, int(on)))

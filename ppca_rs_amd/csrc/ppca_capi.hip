@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -32,10 +33,111 @@ int ppca_host::fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// ---- block cache (DevPool, ppca_handles.hpp)
+static thread_local std::shared_ptr<DevPool> *g_pool = nullptr;
+static std::mutex g_pools_mu;
+static std::vector<std::weak_ptr<DevPool>> g_pools;  // every live pool of the process, for the out-of-memory path
+
+ppca_host::PoolScope::PoolScope(std::shared_ptr<DevPool> &pool) : prev(g_pool) { g_pool = &pool; }
+ppca_host::PoolScope::~PoolScope() { g_pool = prev; }
+
+static size_t pool_round(size_t bytes) {
+    const size_t q = bytes >= (size_t(1) << 20) ? (size_t(2) << 20) : 512;
+    return (std::max<size_t>(bytes, 8) + q - 1) / q * q;
+}
+void *DevPool::take(size_t cap) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = blocks.lower_bound(cap);
+    if (it == blocks.end() || it->first > cap + cap / 4) return nullptr;
+    void *p = it->second;
+    cached -= it->first;
+    blocks.erase(it);
+    return p;
+}
+void DevPool::give(void *p, size_t cap) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (!alive || cap > limit) {
+        lk.unlock();
+        (void)hipFree(p);
+        return;
+    }
+    (void)hipStreamSynchronize(stream);  // what hipFree guaranteed: nothing queued still touches the block
+    std::vector<void *> evict;
+    while (cached + cap > limit && !blocks.empty()) {  // largest first: the small blocks are the often-reused ones
+        auto last = std::prev(blocks.end());
+        cached -= last->first;
+        evict.push_back(last->second);
+        blocks.erase(last);
+    }
+    blocks.emplace(cap, p);
+    cached += cap;
+    lk.unlock();
+    for (void *q : evict) (void)hipFree(q);
+}
+size_t DevPool::trim() {
+    std::vector<void *> all;
+    size_t bytes;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &b : blocks) all.push_back(b.second);
+        blocks.clear();
+        bytes = cached;
+        cached = 0;
+    }
+    for (void *q : all) (void)hipFree(q);
+    return bytes;
+}
+void DevPool::shutdown() {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        alive = false;
+        stream = nullptr;
+    }
+    trim();
+}
+static std::shared_ptr<DevPool> make_pool(hipStream_t stream) {
+    auto pool = std::make_shared<DevPool>();
+    pool->stream = stream;
+    size_t free_b = 0, total_b = 0;
+    size_t limit = size_t(64) << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = std::min(limit, total_b / 4);
+    if (const char *e = getenv("PPCA_POOL_GB")) limit = (size_t)(std::max(atof(e), 0.0) * (double)(size_t(1) << 30));
+    pool->limit = limit;
+    std::lock_guard<std::mutex> lk(g_pools_mu);
+    g_pools.erase(std::remove_if(g_pools.begin(), g_pools.end(), [](const std::weak_ptr<DevPool> &w) { return w.expired(); }),
+                  g_pools.end());
+    g_pools.push_back(pool);
+    return pool;
+}
+static void trim_all_pools() {
+    std::vector<std::shared_ptr<DevPool>> live;
+    {
+        std::lock_guard<std::mutex> lk(g_pools_mu);
+        for (auto &w : g_pools)
+            if (auto sp = w.lock()) live.push_back(sp);
+    }
+    for (auto &sp : live) sp->trim();
+}
+
 int ppca_host::dev_alloc(size_t bytes, BufRef *out) {
     auto b = std::make_shared<DevBuf>();
-    if (bytes == 0) bytes = 8;
-    HIP_TRY(hipMalloc(&b->p, bytes));
+    std::shared_ptr<DevPool> pool = g_pool ? *g_pool : nullptr;
+    if (pool && pool->limit == 0) pool = nullptr;
+    b->cap = pool ? pool_round(bytes) : std::max<size_t>(bytes, 8);
+    if (pool) b->p = pool->take(b->cap);
+    if (!b->p) {
+        hipError_t e = hipMalloc(&b->p, b->cap);
+        if (e == hipErrorOutOfMemory) {  // cached blocks of this or another context may be what is in the way
+            (void)hipGetLastError();
+            trim_all_pools();
+            e = hipMalloc(&b->p, b->cap);
+        }
+        if (e != hipSuccess) {
+            b->p = nullptr;
+            return fail(PPCA_ERR_HIP, "hipMalloc of %zu bytes failed: %s", b->cap, hipGetErrorString(e));
+        }
+    }
+    b->pool = pool;
     *out = b;
     return PPCA_OK;
 }
@@ -103,6 +205,7 @@ extern "C" int ppca_ctx_create(int32_t device_id, void *stream, ppca_ctx **out) 
         }
         ctx->own_stream = true;
     }
+    ctx->pool = make_pool(ctx->stream);
     size_t cap = 0;
     if (ensure(ctx->work, cap, 2048 * sizeof(double))) {
         delete ctx;
@@ -120,8 +223,17 @@ extern "C" int ppca_ctx_destroy(ppca_ctx *ctx) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
+    if (ctx->pool) ctx->pool->shutdown();  // buffers that outlive the context (datasets, models) fall back to hipFree
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_ctx_trim(ppca_ctx *ctx, int64_t *released_bytes) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "ctx is null");
+    USE_CTX(ctx);
+    const size_t got = ctx->pool ? ctx->pool->trim() : 0;
+    if (released_bytes) *released_bytes = (int64_t)got;
     return PPCA_OK;
 }
 
@@ -138,6 +250,10 @@ extern "C" int ppca_ctx_set_stream(ppca_ctx *ctx, void *stream) {
     } else {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
+    }
+    if (ctx->pool) {
+        std::lock_guard<std::mutex> lk(ctx->pool->mu);
+        ctx->pool->stream = ctx->stream;
     }
     return PPCA_OK;
 }

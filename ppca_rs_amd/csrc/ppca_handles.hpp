@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <memory>
 #include <mutex>
 #include <utility>
@@ -12,12 +13,37 @@
 #include "../../include/ppca_hip.h"
 #include "ppca_internal.hpp"
 
+// Block cache of one context.  hipMalloc / hipFree of the multi-GB buffers this library hands out (an N x d output
+// dataset is 8 GB at N = 4 M) cost 0.2-0.4 s a pair -- 30x the kernel that fills them -- so blocks released by a
+// context's buffers are kept and handed to its next allocation of about the same size.  Reuse is ordered by the
+// context's one stream; give() waits for that stream first, which is the guarantee hipFree gave (work still queued
+// against the block finishes before anybody else can own it).  Bounded by `limit` bytes (PPCA_POOL_GB, default
+// min(64 GiB, a quarter of the device)); emptied by ppca_ctx_trim, by ppca_ctx_destroy, and by any allocation of the
+// process that hipMalloc refuses for lack of memory.
+struct DevPool {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    bool alive = true;
+    size_t cached = 0, limit = 0;
+    std::multimap<size_t, void *> blocks;  // capacity -> block
+    void *take(size_t cap);
+    void give(void *p, size_t cap);
+    size_t trim();
+    void shutdown();
+};
+
 struct DevBuf {
     void *p = nullptr;
     bool owned = true;
     int device = 0;
+    size_t cap = 0;
+    std::shared_ptr<DevPool> pool;  // where the block goes back to (nullptr: hipFree)
     ~DevBuf() {
-        if (p && owned) (void)hipFree(p);
+        if (!p || !owned) return;
+        if (pool)
+            pool->give(p, cap);
+        else
+            (void)hipFree(p);
     }
 };
 typedef std::shared_ptr<DevBuf> BufRef;
@@ -28,6 +54,7 @@ struct ppca_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cu = 256;
+    std::shared_ptr<DevPool> pool;  // block cache behind dev_alloc while USE_CTX(this) is in scope
     bool timing = false;
     int skip_llk = 0;  // internal: set around the mixture's component EM steps (PassArgs::no_llk)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -72,6 +99,12 @@ int dev_alloc(size_t bytes, BufRef *out);
 BufRef dev_borrow(const void *p);
 int ensure(BufRef &b, size_t &cap, size_t bytes);
 int use_device(const ppca_ctx *ctx);
+// dev_alloc draws from (and its buffers return to) the innermost scope's pool on this thread
+struct PoolScope {
+    std::shared_ptr<DevPool> *prev;
+    explicit PoolScope(std::shared_ptr<DevPool> &pool);
+    ~PoolScope();
+};
 }  // namespace ppca_host
 
 #define HIP_TRY(expr)                                                                                              \
@@ -86,4 +119,5 @@ int use_device(const ppca_ctx *ctx);
 // Across calls the single stream orders the reuse of the scratch.  Recursive: entry points build on each other.
 #define USE_CTX(c)                                            \
     std::lock_guard<std::recursive_mutex> ctx_lock_((c)->mu); \
+    ppca_host::PoolScope pool_scope_((c)->pool);              \
     if (int rc_ = ppca_host::use_device(c)) return rc_

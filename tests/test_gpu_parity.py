@@ -955,3 +955,30 @@ def test_full_size_properties_config5(P):
             np.testing.assert_array_equal(new.log_weights, again.log_weights)
         mix = new
         assert abs(np.exp(mix.log_weights).sum() - 1.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_block_cache_reuses_and_trims(P):
+    """Output datasets come from the context's block cache (ppca_ctx_trim, include/ppca_hip.h): a released block is
+    handed to the next allocation of its size, results do not depend on what the block held before, and trim gives
+    the memory back.  A private context so that other tests' blocks do not enter the count."""
+    from ppca_rs_amd import _lib
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(5)
+    n, d, k = 40_000, 64, 5
+    truth = P.PPCAModel(0.1, rng.standard_normal((d, k)), rng.standard_normal(d))
+    ds = P.Dataset(truth.sample(n, 0.3, seed=3).numpy(), ctx=ctx)
+    model = P.PPCAModel.init(k, ds, seed=1).iterate(ds)
+    assert ctx.trim() >= 0
+    first = model.smooth(ds)
+    want = first.numpy()
+    del first                                   # the N x d block goes back to the cache ...
+    junk = model.extrapolate(ds)                # ... is drawn and dirtied by another pass ...
+    del junk
+    again = model.smooth(ds)                    # ... and drawn again
+    np.testing.assert_array_equal(again.numpy(), want)
+    del again
+    released = ctx.trim()
+    assert released >= n * d * 8, released
+    assert ctx.trim() == 0
+    np.testing.assert_array_equal(model.smooth(ds).numpy(), want)
