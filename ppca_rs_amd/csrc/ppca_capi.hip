@@ -885,8 +885,27 @@ static int run_post(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, do
         a.recon_mode = recon_mode;
         if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
         fused_qtab_layout(ctx->qtab->p, a);
+#ifdef PPCA_PHASE_TIMING
+        BufRef dbg;
+        if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 16, &dbg)) return rc;
+        HIP_TRY(hipMemsetAsync(dbg->p, 0, sizeof(double) * (size_t)grid * 16, ctx->stream));
+        a.dbg = static_cast<double *>(dbg->p);
+#endif
         HIP_TRY(launch_pass_post(model->k, grid, a, ctx->stream));
         HIP_TRY(launch_reduce_partials(scal, grid, 8, scal + (size_t)grid * 8, ctx->stream));
+#ifdef PPCA_PHASE_TIMING
+        if (!states_dev && !covs_dev && !recon_dev) {
+            std::vector<double> h((size_t)grid * 16);
+            HIP_TRY(hipMemcpyAsync(h.data(), a.dbg, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            double t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int g = 0; g < grid; ++g)
+                for (int i = 0; i < 16; ++i) t[i] += h[(size_t)g * 16 + i] / grid;
+            const double tiles = (double)((ds->n + FUSED_TILE - 1) / FUSED_TILE) / grid;
+            fprintf(stderr, "[llk2 cycles/tile, thread 0] stage+issue %.0f  barriers %.0f  contract: masks+b %.0f, gram %.0f, stores %.0f  solver %.0f  loop %.0f  (tiles/WG %.1f)\n",
+                    t[0] / tiles, t[1] / tiles, t[4] / tiles, t[5] / tiles, t[2] / tiles, t[3] / tiles, t[7] / tiles, tiles);
+        }
+#endif
     }
     if (scal_out) *scal_out = scal + (size_t)grid * 8;
     return PPCA_OK;

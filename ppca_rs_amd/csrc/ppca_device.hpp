@@ -1,4 +1,4 @@
-// ppca_device.hpp -- device-side helpers shared by the fused-pass kernels (ppca_kernels.hip, ppca_em_roles.hip):
+// ppca_device.hpp -- device-side helpers shared by the fused-pass kernels (ppca_kernels.hip, ppca_llk.hip):
 // the LDS layout constants of a 32-sample tile, wave reductions on the DPP path, lane-targeted writes, compile-time
 // loops, the fp64 MFMA wrapper and the constants of the int8-sliced Gram table.  Not installed.
 #pragma once
@@ -79,6 +79,13 @@ template <int LANE>
 __device__ __forceinline__ int writelane_s(int dst, int sval) {
     asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sval), "n"(LANE));
     return dst;
+}
+// Both halves of a 64-bit wave mask (a v_cmp ballot) into lane LANE of two VGPRs; one s_nop covers the hazard for both.
+template <int LANE>
+__device__ __forceinline__ void writelane_mask(int &dlo, int &dhi, unsigned long long m) {
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(dlo), "+v"(dhi)
+        : "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "n"(LANE));
 }
 // mask bit of the lane ? v : 0.0 with the wave mask taken straight from its SGPR pair (a C++ select on
 // (mask >> lane) & 1 would rebuild the predicate with vector shifts).

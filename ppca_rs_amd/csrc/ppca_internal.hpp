@@ -58,11 +58,6 @@ int fused_gram_tiles(int k);  // number of qflag entries the guard writes for st
 // Launchers.  Return hipSuccess or the launch error.
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s);
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);
-// The EM pass as an 8-wave workgroup with front / accumulator roles (ppca_em_roles.hip); honours a.qflag like the
-// int8 instantiation of pass_kernel (returns at once when the guard selects the fp64 Gram).
-hipError_t launch_em_roles(int k, int grid, const PassArgs &a, hipStream_t s);
-// The EM pass with two tiles per round (ppca_em2.hip; k >= 2, no row list); honours a.qflag.
-hipError_t launch_em2(int k, int grid, const PassArgs &a, hipStream_t s);
 // The log-likelihood sweep alone (ppca_llk.hip): per-sample llks (nullable) and the per-workgroup scalars; honours
 // a.qflag like the int8 instantiation of pass_kernel.
 hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s);

@@ -141,7 +141,11 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     union { signed char b8[QS][16]; i4_t v[QS]; } dg;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
-        const int jd = j0 + jj;
+        // k index j0 + jj of the contraction <-> bit (j0 + jj) % 64 of mask word (j0 + jj) / 64 of a sample; the
+        // staging leaves the finite-test ballots as they come (lane l of ballot 2 h + e tested dim 128 h + 2 l + e),
+        // so word q = 2 h + e, bit l is dim 128 h + 2 l + e: the order of a sum is free, the table follows the masks
+        const int kk = j0 + jj;
+        const int jd = 128 * (kk >> 7) + 2 * (kk & 63) + ((kk >> 6) & 1);
         double q = 0.0;
         if (c < KP && jd < d) q = model[MODEL_HDR + (int64_t)jd * K + a] * model[MODEL_HDR + (int64_t)jd * K + b];
         if (!(fabs(q) < 1.0e300)) q = 0.0;
@@ -275,12 +279,10 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     double xr[RPW][4];
     // Row loads are unconditional (clamped to real rows; nothing between issue and first use, so a whole
     // tile's loads stay in flight); out-of-range rows / dims are masked when consumed in P1.
-    bool dim_ok[4];
+    // observed <=> |x| < lim: +inf for a real dimension (finite test, dataset.rs:19-22), -1 for the padding past d
+    double lim[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dim_ok[q] = 128 * (q >> 1) + 2 * lane + (q & 1) < d;
-    unsigned long long dimmask[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dimmask[q] = __builtin_amdgcn_ballot_w64(dim_ok[q]);
+    for (int q = 0; q < 4; ++q) lim[q] = (128 * (q >> 1) + 2 * lane + (q & 1) < d) ? __builtin_inf() : -1.0;
     // Each workgroup walks a CONTIGUOUS run of tiles (consecutive 64 KB pieces of X share pages, unlike a
     // grid-strided walk that starts every tile 16 MB further on).
     const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -289,6 +291,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     const int64_t nleft = n - tile_begin * B;
     const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));  // rows from the workgroup's first row to the end
     const double *Xwg = p.X + tile_begin * B * p.ldx;
+    // real rows of the workgroup's own tiles, counted from its first row
+    const int64_t own = (tile_end - tile_begin) * B;
+    const int nmine = tile_end > tile_begin ? (int)(own < nleft ? own : nleft) : 0;
     constexpr bool CAN_GATHER = EM && NW == 4 && (GATHER || !GI8);
     const int *rows_wg = (CAN_GATHER && p.rows) ? p.rows + tile_begin * B : nullptr;
     const int lane_entry = lane;
@@ -383,14 +388,13 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 pc_xx = 0.0;
                 pc_m = 0;
             }
-            // wave-uniform; the tile staged behind the workgroup's last P4 is another workgroup's (or none)
-            const bool row_ok = t < tile_end && (int)(t - tile_begin) * B + ri < nrel;
+            // Rows past n (the clamped last row again) and the tile staged behind the workgroup's last P4 (another
+            // workgroup's, or none) are staged like any other: every consumer weighs them with zero or skips them.
+            // The compare's wave mask IS the ballot and feeds the select directly -- no scalar instruction between.
             const double v = xr[r][q];
-            // the finite test's wave mask IS the ballot; validity is ANDed in on the scalar unit
-            // (|v| < inf as llvm.amdgcn.fcmp, predicate 4 = OLT: one v_cmp_lt_f64 straight into an SGPR pair;
-            //  ballot(isfinite) goes through v_cmp_class + v_cndmask + v_cmp_ne)
-            const unsigned long long bal = __builtin_amdgcn_fcmp(__builtin_fabs(v), __builtin_inf(), 4) & (row_ok ? dimmask[q] : 0ull);
-            const double xt = keep_if(v - mu[q], bal);  // select, never multiply (utils.rs:118-127)
+            const bool ob = __builtin_fabs(v) < lim[q];
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(ob);
+            const double xt = ob ? v - mu[q] : 0.0;  // select, never multiply (utils.rs:118-127)
             if constexpr (e == 0) {
                 pc_b0 = bal;
                 pc_xt0 = xt;
@@ -400,20 +404,11 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             }
         } else if constexpr (P == 2 || P == 5) {  // file half h: mask words, x~ pair, sums
             constexpr int h = (P == 2) ? 0 : 1;
-            // lane l tested dims 128 h + 2 l (pc_b0) and + 1 (pc_b1): the two 64-dim mask words are the bit
-            // interleaves of the ballots' low and high halves (s_bitreplicate doubles every bit; scalar unit)
-            auto weave = [&](unsigned ev, unsigned od) {
-                unsigned long long re, ro;
-                asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(re) : "s"(ev));
-                asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(ro) : "s"(od));
-                return (re & 0x5555555555555555ull) | (ro & 0xAAAAAAAAAAAAAAAAull);
-            };
-            const unsigned long long w0 = weave((unsigned)pc_b0, (unsigned)pc_b1);
-            const unsigned long long w1 = weave((unsigned)(pc_b0 >> 32), (unsigned)(pc_b1 >> 32));
-            st_wlo = writelane_s<4 * r + 2 * h>(st_wlo, (int)(unsigned)w0);
-            st_whi = writelane_s<4 * r + 2 * h>(st_whi, (int)(unsigned)(w0 >> 32));
-            st_wlo = writelane_s<4 * r + 2 * h + 1>(st_wlo, (int)(unsigned)w1);
-            st_whi = writelane_s<4 * r + 2 * h + 1>(st_whi, (int)(unsigned)(w1 >> 32));
+            // mask word 2 h + e of the row = the ballot of element 2 h + e (bit l <-> dim 128 h + 2 l + e); the
+            // readers index it that way (P2: any order of a sum, qprep lays the table out to match; P4b / output
+            // pass: word by the parity of the dimension)
+            writelane_mask<4 * r + 2 * h>(st_wlo, st_whi, pc_b0);
+            writelane_mask<4 * r + 2 * h + 1>(st_wlo, st_whi, pc_b1);
             typedef double d2_t __attribute__((ext_vector_type(2)));
             *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 * h + 2 * lane) = d2_t{pc_xt0, pc_xt1};  // 16-byte aligned
             pc_xx += pc_xt0 * pc_xt0;
@@ -422,8 +417,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         } else if constexpr (P == 6) {
             st_m = writelane<r>(st_m, pc_m);
             if constexpr (EM) {
-                const int64_t row = t * B + ri;
-                const double wr = p.w ? p.w[row < n ? row : n - 1] : 1.0;  // wave-uniform (scalar load)
+                // wave-uniform: a real row of one of THIS workgroup's tiles (32-bit compare on the scalar unit)
+                const bool mine = (int)(t - tile_begin) * B + ri < nmine;
+                const double wr = mine ? (p.w ? p.w[t * B + ri] : 1.0) : 0.0;  // (scalar load)
                 xx_run += wr * pc_xx;
             }
         } else if constexpr (P == 7) {
@@ -487,9 +483,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         {
             const int rt = wave & 1, kq = wave >> 1;
             const int si = 16 * rt + l15;
-            unsigned long long mw[WPS];
-#pragma unroll
-            for (int i = 0; i < WPS; ++i) mw[i] = Msc[si * 4 + WPS * kq + i];
+            // fp64 Gram: the lane's dims DPS kq + 4 s + l4 all sit in ONE mask word (parity l4 & 1), bits 2 s apart
+            const unsigned long long mwsel = Msc[si * 4 + 2 * ((DPS * kq) >> 7) + (l4 & 1)];
+            const int mwbit = (((DPS * kq) & 127) >> 1) + (l4 >> 1);
             d4_t acc[NTM];
 #pragma unroll
             for (int t = 0; t < NTM; ++t) acc[t] = d4_t{0, 0, 0, 0};
@@ -590,7 +586,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             for (int s = 0; s < (GI8 ? 0 : STEPS); ++s) {
                 const double ax = xrow[4 * s];
                 if constexpr (!GI8) {
-                    const double am = ((mw[s / 16] >> (4 * (s & 15) + l4)) & 1ull) ? 1.0 : 0.0;
+                    const double am = ((mwsel >> (mwbit + 2 * s)) & 1ull) ? 1.0 : 0.0;
 #pragma unroll
                     for (int t = 0; t < NTP; ++t)
                         acc[t] = mfma(am, cpa[t][4 * s * CS] * cpb[t][4 * s * CS], acc[t]);
@@ -798,7 +794,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 // across P4 as well spills 73 registers
                 if (PREFETCH_A) load_pair(qbA, 6);
             }
-            unsigned long long mwc = Msc[l4 * 4 + (DW * wave) / 64];
+            // mask operand of dims DW wave + 16 r + l15: word 2 (dim / 128) + parity, bit (dim % 128) / 2
+            const int mword = 2 * ((DW * wave) >> 7) + (l15 & 1);
+            unsigned long long mwc = Msc[l4 * 4 + mword];
             double bwc[NTMB], bsc = 0.0;
 #pragma unroll
             for (int t = 0; t < NTMB; ++t) bwc[t] = Ws[l4 * WS + 16 * t + l15];
@@ -819,8 +817,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 static_for<SLOTS>([&](auto i_tag) {
                     constexpr int i = decltype(i_tag)::value, r = i / PER_R, t = i % PER_R;
                     // am = bit ? 1.0 : 0.0 in two ops: sign-extended 1-bit field (0 / -1) & high word of 1.0
-                    const int sh = ((DW * wave) & 63) + 16 * r;
-                    const int am_hi = __builtin_amdgcn_sbfe((int)(unsigned)(mwc >> (sh & 32)), (sh & 31) + l15, 1) & 0x3FF00000;
+                    const int sh = (((DW * wave) & 127) >> 1) + 8 * r;
+                    const int am_hi = __builtin_amdgcn_sbfe((int)(unsigned)(mwc >> (sh & 32)), (sh & 31) + (l15 >> 1), 1) & 0x3FF00000;
                     const double am = __hiloint2double(am_hi, 0);
                     if constexpr (t < NTMB) {
                         accM[r][t] = mfma(am, bwc[t], accM[r][t]);
@@ -835,7 +833,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     }
                     if constexpr (i == SLOTS * 3 / 4 && s + 1 < 8) {
                         const int smp = 4 * (s + 1) + l4;
-                        mwn = Msc[smp * 4 + (DW * wave) / 64];
+                        mwn = Msc[smp * 4 + mword];
 #pragma unroll
                         for (int tt = 0; tt < NTMB; ++tt) bwn[tt] = Ws[smp * WS + 16 * tt + l15];
                         if constexpr (SPLIT) bsn = Ws[smp * WS + 16 * NTP + PADS + (lane & 3)];
@@ -951,7 +949,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int j = 64 * q + lane;
-                    const bool obs = (Msc[ri * 4 + q] >> lane) & 1ull;
+                    const bool obs = (Msc[ri * 4 + 2 * (q >> 1) + (lane & 1)] >> (32 * (q & 1) + (lane >> 1))) & 1ull;
                     double out = Xs[ri * XS + j];
                     if (extra) out = obs ? xin[rr][q] : out;
                     if (zero_obs) out = obs ? 0.0 : out;
@@ -1381,28 +1379,10 @@ static int gram_mode() {
     return v;
 }
 
-static bool em2_enabled() {  // PPCA_EM2=1: the two-tile EM kernel (ppca_em2.hip)
-    static const bool v = [] {
-        const char *e = getenv("PPCA_EM2");
-        return e && atoi(e) == 1;
-    }();
-    return v;
-}
-
 static bool llk2_enabled() {
     static const bool v = [] {
         const char *e = getenv("PPCA_LLK2");
         return !(e && atoi(e) == 0);
-    }();
-    return v;
-}
-
-// PPCA_EM_ROLES=1 selects the role-split 8-wave EM kernel (ppca_em_roles.hip): bit-identical statistics, measured
-// 71.2 vs 71.8 EM it/s at N = 10 M -- kept as a measured alternative, see the note at the top of that file.
-static bool em_roles() {
-    static const bool v = [] {
-        const char *e = getenv("PPCA_EM_ROLES");
-        return e && atoi(e) == 1;
     }();
     return v;
 }
@@ -1421,13 +1401,7 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
     }
 #endif
     hipLaunchKernelGGL((qprep_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab, a.qflag);
-    // EM pass: the role-split 8-wave kernel (ppca_em_roles.hip) when PPCA_EM_ROLES=1
-    const bool roles = EM && em_roles() && !a.rows;
     auto int8_pass = [&](const PassArgs &b) {
-        if (roles) return launch_em_roles(K, grid, b, s);
-        if constexpr (EM && K >= 2) {
-            if (!b.rows && em2_enabled()) return launch_em2(K, grid, b, s);
-        }
         if constexpr (!EM) {  // llk / llks alone: the two-tile sweep (ppca_llk.hip) unless PPCA_LLK2=0
             if (!b.states && !b.covs && !b.recon && llk2_enabled()) return launch_llk2(K, grid, b, s);
         }

@@ -5,16 +5,26 @@
 //
 // pass_kernel<K, false, ...> serves this request with its general machinery: a 32-sample tile, the solver on 32 of 64
 // lanes in every one of four waves, z by two substitutions, and room for the posterior / reconstruction outputs.  The
-// llk of a sample needs only  m, |x~|^2, ln det M  and  quad = b^T M^-1 b = |L^-1 b|^2:
+// llk of a sample needs only  m, |x~|^2, ln det M  and  quad = b^T M^-1 b = |L^-1 b|^2, and with one wave per SIMD
+// every instruction of a wave -- scalar ones included -- costs an issue slot of ~4 cycles (measured: the staging of a
+// tile took 4.07 cycles per instruction of any kind), so this kernel is built to issue few of them:
 //   * TWO tiles per round: P1 / P2 of tile A, P1 / P2 of tile B (the x~ tile is free again after a tile's P2: nothing
-//     reads it later in this pass), then ONE solver step for the 64 samples on all 64 lanes of wave 0 -- the other
-//     waves have no share in it (there are no M^-1 columns to compute) and wait at the barrier;
-//   * factorisation + the forward substitution only;
+//     reads it later in this pass), then ONE solver step for the 64 samples on all 64 lanes of wave 0 -- factorisation
+//     + the forward substitution only; the observed counts are popcounts of the mask words, taken there;
+//   * the wave's slice of the int8 digit table (8 slices x 4 k-chunks x 16 bytes per lane = 128 registers; there are
+//     no statistics accumulators in this pass) is loaded ONCE per workgroup and stays in registers: no table traffic
+//     and no load latency inside the tile loop;
+//   * staging without scalar work: the finite test |x| < lim (lim = +inf, or -1 for the padding past d) gives the wave
+//     mask that is both the select predicate and, as it comes, mask word 2 h + e of the row (qprep orders the table
+//     rows to match); a tile's rows are addressed through ONE buffer descriptor with a scalar offset per row (rows
+//     past the end read as zeros and are never somebody's sample); the eight per-lane |x~|^2 partials of a wave's rows
+//     are summed together (v_permlane32_swap / v_permlane16_swap fold two rows per add, then four DPP steps for the
+//     last two registers) instead of one six-step reduction per row;
 //   * the next tile's rows are requested as soon as the registers of the previous one are staged, so they travel
 //     under a whole P2.
-// Per-sample arithmetic is that of pass_kernel (same staging, same int8-sliced Gram behind the same guard, same
-// Cholesky), so the llks agree with it to rounding of the final sum (quad is summed from the forward unknowns in the
-// same order).  The guard's fallback is pass_kernel<K, false, 4, false>.
+// Per-sample arithmetic is that of pass_kernel except for the ORDER of the |x~|^2 sum (same int8-sliced Gram behind
+// the same guard, same Cholesky), so the llks agree with it to rounding.  The guard's fallback is
+// pass_kernel<K, false, 4, false>.
 #include <atomic>
 #include <cstdlib>
 
@@ -32,19 +42,34 @@ struct CfgL {
     static constexpr int OFF_C = OFF_X + B * XS;
     static constexpr int OFF_G = OFF_C + DP * CS;
     static constexpr int OFF_B1 = OFF_G + 2 * B * GS;
-    static constexpr int OFF_M = OFF_B1 + 2 * B * BS;   // mask words of the tile being contracted, B x 4 u64
-    static constexpr int OFF_XX = OFF_M + B * 4;        // |x~|^2 of the 2 B samples
-    static constexpr int OFF_MC = OFF_XX + 2 * B;       // observed counts, 2 B ints
-    static constexpr int OFF_R = OFF_MC + B;            // cross-wave scratch
-    static constexpr int LDS_DOUBLES = OFF_R + 16;
+    static constexpr int OFF_M = OFF_B1 + 2 * B * BS;   // mask words of the round's two tiles, 2 B x 4 u64
+    static constexpr int OFF_XX = OFF_M + 2 * B * 4;    // |x~|^2 of the 2 B samples
+    static constexpr int LDS_DOUBLES = OFF_XX + 2 * B;
 };
+
+// a (lanes 0-31 | 32-63), b -> lanes 0-31: a_lo + a_hi, lanes 32-63: b_lo + b_hi (v_permlane32_swap exchanges the
+// upper half of its first operand with the lower half of its second)
+__device__ __forceinline__ double fold_halves(double a, double b) {
+    const long long ab = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ab, (unsigned)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
+    return __longlong_as_double(((long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
+}
+// rows of 16 lanes (r0 r1 r2 r3): -> rows 0, 2: a_even + a_odd, rows 1, 3: b_even + b_odd (v_permlane16_swap exchanges
+// the odd rows of its first operand with the even rows of its second)
+__device__ __forceinline__ double fold_rows(double a, double b) {
+    const long long ab = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ab, (unsigned)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
+    return __longlong_as_double(((long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
+}
 
 template <int K>
 __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
     using cfg = CfgL<K>;
     constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS, BS = cfg::BS;
     constexpr int NW = 4, RPW = B / NW, DPS = cfg::DP / 2, STEPS = DPS / 4;
-    static_assert(NTP <= NW && QS == 8, "int8 Gram: one wave per packed-column tile, 8 digit slices");
+    static_assert(NTP <= NW && QS == 8 && RPW == 8, "int8 Gram: one wave per packed-column tile, 8 digit slices; 8 rows per wave");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Xs = sm + cfg::OFF_X;
     double *Cs = sm + cfg::OFF_C;
@@ -52,7 +77,6 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
     double *B1 = sm + cfg::OFF_B1;
     unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
     double *xxs = sm + cfg::OFF_XX;
-    int *mcnt = reinterpret_cast<int *>(sm + cfg::OFF_MC);
 
     if (p.qflag) {  // qprep's dynamic-range guard: pass_kernel<K, false, 4, false> runs instead
         int unsafe = 0;
@@ -71,114 +95,110 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
         int j = idx / CS, a = idx - j * CS;
         Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
     }
-    double mu[4];  // staging lane map: lane l holds dims 128 h + 2 l + e (element q = 2 h + e) of a row
+    // staging lane map: lane l holds dims 128 h + 2 l + e (element q = 2 h + e) of a row; observed <=> |x| < lim
+    double mu[4], lim[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        int j = 128 * (q >> 1) + 2 * lane_entry + (q & 1);
+        const int j = 128 * (q >> 1) + 2 * lane_entry + (q & 1);
         mu[q] = (j < d) ? mMean[j] : 0.0;
+        lim[q] = (j < d) ? __builtin_inf() : -1.0;
     }
-    bool dim_ok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dim_ok[q] = 128 * (q >> 1) + 2 * lane_entry + (q & 1) < d;
-    unsigned long long dimmask[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dimmask[q] = __builtin_amdgcn_ballot_w64(dim_ok[q]);
 
     const int64_t ntiles = (n + B - 1) / B;
     const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
     const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
     const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
     const int64_t nleft = n - tile_begin * B;
-    const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));
+    const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));  // rows from the workgroup's first row to the end
     const double *Xwg = p.X + tile_begin * B * p.ldx;
+    const int rowbytes = d * (int)sizeof(double);  // rows are contiguous (ldx == d)
+#ifdef PPCA_PHASE_TIMING
+    long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define LLK_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define LLK_STAMP(i)
+#endif
     double xr[RPW][4];
-    auto load_tile = [&](int64_t tile) {  // unconditional (rows clamped to real ones; validity applied when staged)
+    // One descriptor per tile (base = its first row, extent = its real rows): the row is a scalar offset, the lane
+    // a constant VGPR, the half an immediate.  Rows past n read as zeros ("observed", but no lane's sample).
+    auto load_tile = [&](int64_t tile) {
+        const int rel0 = (int)(tile - tile_begin) * B;
+        int cnt = nrel - rel0;
+        cnt = __builtin_amdgcn_readfirstlane(cnt < 0 ? 0 : (cnt > B ? B : cnt));  // (keeps the descriptor scalar)
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(Xwg + (int64_t)rel0 * p.ldx), 0, cnt * rowbytes, 0x00020000);
+        const int wbase = wave * RPW * rowbytes;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const int rel = (int)(tile - tile_begin) * B + wave * RPW + r;
-            const int rc = nrel > 0 ? (rel < nrel ? rel : nrel - 1) : 0;
-            const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<double *>(Xwg + (int64_t)rc * p.ldx), 0, nrel > 0 ? d * (int)sizeof(double) : 0, 0x00020000);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, 0);
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, wbase + r * rowbytes + 1024 * h, 0);
                 xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
                 xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
             }
         }
     };
-    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
+    // The wave's slice of the digit table, resident: fragment (slice sl, k-chunk kc) = 16 bytes per lane.  Waves
+    // without a column tile (k' <= 48) read past the table (zeros), run the same MFMAs and skip only the store.
     const bool gram_wave = NTP >= NW || wave < NTP;
-    auto load_pair = [&](i4_t(&dst)[2][4], int sl0) {
-        int qbase = wave * QS * 4 * 1024;
-        asm volatile("" : "+s"(qbase));
+    i4_t qt[QS][4];
+    {
+        const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
+        const int qbase = wave * QS * 4 * 1024;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int sl = 0; sl < QS; ++sl)
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16, qbase + ((sl0 + u) * 4 + kc) * 1024, 0);
-                dst[u][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16, qbase + (sl * 4 + kc) * 1024, 0);
+                qt[sl][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
             }
-    };
+    }
+    const double qs = gram_wave ? p.qscale[16 * wave + (lane_entry & 15)] : 0.0;
 
-    // ---- P1: stage one tile (slot 0 / 1 of the round): x~ into the LDS tile, mask words, |x~|^2 and counts per sample
-    auto stage_tile = [&](int64_t t, int lane, int slot) {
-        int st_wlo = 0, st_whi = 0, st_m = 0, st_xlo = 0, st_xhi = 0;
+    // ---- P1: stage one tile (slot 0 / 1 of the round): x~ into the LDS tile, mask words, |x~|^2 per sample
+    auto stage_tile = [&](int lane, int slot) {
+        int st_wlo = 0, st_whi = 0;
+        double pxx[RPW];
         static_for<RPW>([&](auto r_tag) {
             constexpr int r = decltype(r_tag)::value;
             const int ri = wave * RPW + r;
-            const bool row_ok = t < tile_end && (int)(t - tile_begin) * B + ri < nrel;  // wave-uniform
             double xt[4];
-            unsigned long long bal[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            static_for<4>([&](auto q_tag) {
+                constexpr int q = decltype(q_tag)::value;
                 const double v = xr[r][q];
-                // observed <=> finite (dataset.rs:19-22): |v| < inf straight into an SGPR pair
-                bal[q] = __builtin_amdgcn_fcmp(__builtin_fabs(v), __builtin_inf(), 4) & (row_ok ? dimmask[q] : 0ull);
-                xt[q] = keep_if(v - mu[q], bal[q]);  // select, never multiply (utils.rs:118-127)
-            }
-            double pc_xx = 0.0;
-            int pc_m = 0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                auto weave = [&](unsigned ev, unsigned od) {
-                    unsigned long long re, ro;
-                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(re) : "s"(ev));
-                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(ro) : "s"(od));
-                    return (re & 0x5555555555555555ull) | (ro & 0xAAAAAAAAAAAAAAAAull);
-                };
-                const unsigned long long b0 = bal[2 * h], b1 = bal[2 * h + 1];
-                const unsigned long long w0 = weave((unsigned)b0, (unsigned)b1);
-                const unsigned long long w1 = weave((unsigned)(b0 >> 32), (unsigned)(b1 >> 32));
-                if (h == 0) {
-                    st_wlo = writelane_s<4 * r>(st_wlo, (int)(unsigned)w0);
-                    st_whi = writelane_s<4 * r>(st_whi, (int)(unsigned)(w0 >> 32));
-                    st_wlo = writelane_s<4 * r + 1>(st_wlo, (int)(unsigned)w1);
-                    st_whi = writelane_s<4 * r + 1>(st_whi, (int)(unsigned)(w1 >> 32));
-                } else {
-                    st_wlo = writelane_s<4 * r + 2>(st_wlo, (int)(unsigned)w0);
-                    st_whi = writelane_s<4 * r + 2>(st_whi, (int)(unsigned)(w0 >> 32));
-                    st_wlo = writelane_s<4 * r + 3>(st_wlo, (int)(unsigned)w1);
-                    st_whi = writelane_s<4 * r + 3>(st_whi, (int)(unsigned)(w1 >> 32));
-                }
-                typedef double d2_t __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 * h + 2 * lane) = d2_t{xt[2 * h], xt[2 * h + 1]};
-                pc_xx += xt[2 * h] * xt[2 * h];
-                pc_xx += xt[2 * h + 1] * xt[2 * h + 1];
-                pc_m += __popcll(b0) + __popcll(b1);
-            }
-            st_m = writelane<r>(st_m, pc_m);
-            const long long tb = __double_as_longlong(wave_total(pc_xx));
-            st_xlo = writelane<r>(st_xlo, (int)tb);  // (wave-uniform by v_readlane: the padded form of the lane write)
-            st_xhi = writelane<r>(st_xhi, (int)(tb >> 32));
+                const bool ob = __builtin_fabs(v) < lim[q];  // finite (dataset.rs:19-22) and a real dimension
+                xt[q] = ob ? v - mu[q] : 0.0;                // select, never multiply (utils.rs:118-127)
+                // mask word q of the row = this ballot as it comes (bit l <-> dim 128 h + 2 l + e), into lane 4 r + q
+                writelane_mask<4 * r + q>(st_wlo, st_whi, __builtin_amdgcn_ballot_w64(ob));
+            });
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<d2_t *>(Xs + ri * XS + 2 * lane) = d2_t{xt[0], xt[1]};
+            *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 + 2 * lane) = d2_t{xt[2], xt[3]};
+            pxx[r] = xt[0] * xt[0] + xt[1] * xt[1] + xt[2] * xt[2] + xt[3] * xt[3];
         });
         const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
-        if (lane < 4 * RPW) Ms[wave * 4 * RPW + lane] = myw;
-        if (lane < RPW) {
-            xxs[slot * B + wave * RPW + lane] = __longlong_as_double(((long long)st_xhi << 32) | (unsigned)st_xlo);
-            mcnt[slot * B + wave * RPW + lane] = st_m;
+        if (lane < 4 * RPW) Ms[(slot * B + wave * RPW) * 4 + lane] = myw;
+        // eight per-lane partials -> eight row totals: halves, then 16-lane rows, then within the rows
+        double u[4], w2[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = fold_halves(pxx[2 * i], pxx[2 * i + 1]);  // half h: row 2 i + h
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w2[j] = fold_rows(u[2 * j], u[2 * j + 1]);       // 16-lane row rho: row 4 j + 2 (rho & 1) + (rho >> 1)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double v = w2[j];
+            v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+            v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+            v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
+            v += dpp_f64<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+            w2[j] = v;
+        }
+        if ((lane & 15) == 0) {
+            const int rho = lane >> 4, r0 = 2 * (rho & 1) + (rho >> 1);
+            xxs[slot * B + wave * RPW + r0] = w2[0];
+            xxs[slot * B + wave * RPW + 4 + r0] = w2[1];
         }
     };
     // ---- P2: [G | b] of the staged tile into rows slot * B .. of the exchange buffers
@@ -190,47 +210,16 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
         d4_t accb = d4_t{0, 0, 0, 0};
         const double *xrow = Xs + si * XS + DPS * kq + l4;
         const double *cpc = Cs + (DPS * kq + l4) * CS + colb;
-        i4_t af[2][4], qbA[2][4], qbB[2][4];
-        double v[2][4];
-        auto group = [&](const i4_t(*qb)[4], bool first) {
-#pragma unroll
-            for (int rt2 = 0; rt2 < 2; ++rt2) {
-                i4_t ia[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    ia[u] = i4_t{0, 0, 0, 0};
-#pragma unroll
-                    for (int kc = 0; kc < 4; ++kc)
-                        ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt2][kc], qb[u][kc], ia[u], 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int part = ia[1][r] * 128 + ia[0][r];
-                    v[rt2][r] = first ? (double)part : v[rt2][r] * 16384.0 + (double)part;
-                }
-            }
-        };
+        // A = mask bytes: lane (sample = 16 rt2 + l15, k = 64 kc + 16 l4 .. +15 of word kc); 4 bits -> 4 bytes by
+        // one multiply: (x * 0x204081) & 0x01010101 puts bit i of x into byte i
+        i4_t af[2][4];
         unsigned long long mwd[2][4];
 #pragma unroll
         for (int rt2 = 0; rt2 < 2; ++rt2)
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) mwd[rt2][kc] = Ms[(16 * rt2 + l15) * 4 + kc];
-        __builtin_amdgcn_sched_barrier(0);
-        load_pair(qbA, 6);
-        load_pair(qbB, 4);
-        const double qs = gram_wave ? p.qscale[16 * wave + l15] : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rt2 = 0; rt2 < 2; ++rt2)
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const unsigned bits = (unsigned)(mwd[rt2][kc] >> (16 * l4)) & 0xFFFFu;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
-            }
+            for (int kc = 0; kc < 4; ++kc) mwd[rt2][kc] = Ms[(slot * B + 16 * rt2 + l15) * 4 + kc];
         {
-            // b = X~ C first: its 32 fp64 MFMAs cover the arrival of the digit table
+            // b = X~ C first: its operands are requested four k-steps ahead, and the mask words arrive under it
             constexpr int CH = 4;
             double axb[2][CH], cbb[2][CH];
 #pragma unroll
@@ -253,12 +242,40 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        group(qbA, true);   // digits {7,6}
-        load_pair(qbA, 2);
-        group(qbB, false);  // digits {5,4}
-        load_pair(qbB, 0);
-        group(qbA, false);  // digits {3,2}
-        group(qbB, false);  // digits {1,0}
+        LLK_STAMP(4)
+#pragma unroll
+        for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const unsigned bits = (unsigned)(mwd[rt2][kc] >> (16 * l4)) & 0xFFFFu;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
+            }
+        // digit pairs high to low: exact integer sums (|sum| <= 2^14 per digit, two digits per i32), folded into the
+        // running fp64 value by Horner in 128^2
+        double v[2][4];
+#pragma unroll
+        for (int g = 0; g < QS / 2; ++g) {
+            const int sl = QS - 2 - 2 * g;
+#pragma unroll
+            for (int rt2 = 0; rt2 < 2; ++rt2) {
+                i4_t ia[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ia[u] = i4_t{0, 0, 0, 0};
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc)
+                        ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt2][kc], qt[sl + u][kc], ia[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int part = ia[1][r] * 128 + ia[0][r];
+                    v[rt2][r] = g == 0 ? (double)part : v[rt2][r] * 16384.0 + (double)part;
+                }
+            }
+        }
+        LLK_STAMP(5)
         if (gram_wave) {
 #pragma unroll
             for (int rt2 = 0; rt2 < 2; ++rt2)
@@ -279,16 +296,25 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
     for (int64_t tile = tile_begin; tile < tile_end; tile += 2) {
         int lane = lane_entry;
         asm volatile("" : "+v"(lane));
-        stage_tile(tile, lane, 0);
+        LLK_STAMP(7)
+        stage_tile(lane, 0);
         load_tile(tile + 1);  // travels under the contraction below
+        LLK_STAMP(0)
         __syncthreads();
+        LLK_STAMP(1)
         contract_tile(lane, 0);
+        LLK_STAMP(2)
         __syncthreads();
-        stage_tile(tile + 1, lane, 1);
+        LLK_STAMP(1)
+        stage_tile(lane, 1);
         load_tile(tile + 2);
+        LLK_STAMP(0)
         __syncthreads();
+        LLK_STAMP(1)
         contract_tile(lane, 1);
+        LLK_STAMP(2)
         __syncthreads();
+        LLK_STAMP(1)
         if (wave == 0) {
             // ---- P3: lane i < 32 -> sample i of tile, lane i >= 32 -> sample i - 32 of tile + 1
             const int slot = lane >> 5, i = lane & (B - 1);
@@ -298,7 +324,8 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
             const double *g0 = Gs + lane * GS;
             const double *b1 = B1 + lane * BS;
             const double wgt = mine ? (p.w ? p.w[row] : 1.0) : 0.0;
-            const int m = mcnt[lane];
+            const unsigned long long *mw = Ms + lane * 4;
+            const int m = __popcll(mw[0]) + __popcll(mw[1]) + __popcll(mw[2]) + __popcll(mw[3]);
             const double xx = xxs[lane];
             Posterior<K> post;
             double pm;
@@ -310,8 +337,13 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
             run_w += wgt;
             if (p.llks && mine) p.llks[row] = lk;
         }
+        LLK_STAMP(3)
         __syncthreads();
     }
+#ifdef PPCA_PHASE_TIMING
+    if (p.dbg && tid == 0)
+        for (int i = 0; i < 16; ++i) p.dbg[(int64_t)blockIdx.x * 16 + i] = (double)tph[i];
+#endif
     if (wave == 0) {
         const double v2 = wave_sum(run_llk), v3 = wave_sum(run_w);
         if (lane_entry == 0) {

@@ -11,7 +11,8 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
 worst = 0.0
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
-    k = int(rng.integers(1, 11)); d = int(rng.integers(k, 257)); n = int(rng.integers(1, 400))
+    k = int(os.environ.get('PPCA_FUZZ_K', 0)) or int(rng.integers(1, 11)); d = int(rng.integers(k, 257)); n = int(rng.integers(1, 400))
+    if case % 5 == 0: d = 256
     x = rng.standard_normal((n, k)) @ rng.standard_normal((k, d)) + 0.1 * rng.standard_normal((n, d)) + rng.standard_normal(d)
     kind = rng.integers(0, 4)
     if kind == 0: x[rng.random((n, d)) < rng.uniform(0, 0.9)] = np.nan
