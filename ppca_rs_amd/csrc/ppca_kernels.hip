@@ -198,7 +198,6 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     double *Ws = sm + cfg::OFF_W;
     unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
     double *xxs = sm + cfg::OFF_S;
-    int *mcnt = reinterpret_cast<int *>(sm + cfg::OFF_S + B);
 
     if (p.qflag) {  // Gram engine chosen per model by qprep's dynamic-range guard: exactly one of the two variants runs
         int unsafe = 0;
@@ -297,31 +296,46 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     constexpr bool CAN_GATHER = EM && NW == 4 && (GATHER || !GI8);
     const int *rows_wg = (CAN_GATHER && p.rows) ? p.rows + tile_begin * B : nullptr;
     const int lane_entry = lane;
-    // Row loads are buffer loads through a per-row descriptor (base = row start, extent = d doubles): the
-    // address is one scalar multiply-add, the lane offset one constant VGPR, the quarter an immediate --
-    // no vector address arithmetic, and dims past d read as zero.  Rows are indexed relative to the
-    // workgroup's first row so that the clamp to the last real row is a 32-bit scalar compare.
-    auto load_row = [&](int64_t tile, int r) {
-        const int rel = (int)(tile - tile_begin) * B + wave * RPW + r;
-        const int rc = rel < nrel ? rel : nrel - 1;
-        // gathered pass (PassArgs::rows): sample i of the pass is physical row rows[i] -- one scalar load per row
-        const double *rowp = Xwg + (int64_t)rc * p.ldx;
+    // Row loads are buffer loads through ONE descriptor per tile (base = the tile's first row, extent = its real rows;
+    // rows are contiguous, ldx == d): the row is a scalar offset, the lane offset one constant VGPR, the half an
+    // immediate -- no vector address arithmetic and no per-row scalar work.  Rows past n read as zeros: "observed",
+    // but weighted with zero or skipped by every consumer.  The gathered pass (PassArgs::rows: sample i = physical
+    // row rows[i]) builds a descriptor per row from one scalar load.
+    const int rowbytes = d * (int)sizeof(double);
+    auto tile_rsrc = [&](int64_t tile) {
+        const int rel0 = (int)(tile - tile_begin) * B;
+        int cnt = nrel - rel0;
+        cnt = __builtin_amdgcn_readfirstlane(cnt < 0 ? 0 : (cnt > B ? B : cnt));  // (keeps the descriptor scalar)
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Xwg + (int64_t)rel0 * p.ldx), 0, cnt * rowbytes, 0x00020000);
+    };
+    auto load_row = [&](const __amdgpu_buffer_rsrc_t &trs, int64_t tile, int r) {
+        typedef unsigned u4_t __attribute__((ext_vector_type(4)));
         if constexpr (CAN_GATHER) {
-            if (rows_wg) rowp = p.X + (int64_t)rows_wg[rc] * p.ldx;
-        }
-        const __amdgpu_buffer_rsrc_t xrsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rowp), 0, d * (int)sizeof(double), 0x00020000);
+            if (rows_wg) {
+                const int rel = (int)(tile - tile_begin) * B + wave * RPW + r;
+                const int rc = rel < nrel ? rel : nrel - 1;
+                const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<double *>(p.X + (int64_t)rows_wg[rc] * p.ldx), 0, rowbytes, 0x00020000);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {  // validity is applied when consumed (P1)
-            typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, 0);
+                for (int h = 0; h < 2; ++h) {
+                    const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, 0);
+                    xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+                    xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // validity is applied by the consumers (P1: lim; P3 / outputs: row < n)
+            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(trs, lane_entry * 16, (wave * RPW + r) * rowbytes + 1024 * h, 0);
             xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
             xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
         }
     };
     auto load_tile = [&](int64_t tile) {
+        const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile);
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) load_row(tile, r);
+        for (int r = 0; r < RPW; ++r) load_row(trs, tile, r);
     };
     if (tile_begin < tile_end) load_tile(tile_begin);
     // int8 Gram: the slice table of this wave's column tile (QS x 4 fragments of 16 B per lane, L2-resident)
@@ -347,10 +361,19 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16, qbase + ((sl0 + u) * 4 + kc) * 1024, 0);
+                // (the k-chunk rides in the instruction's immediate offset: one scalar offset per slice, not per fragment)
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16 + kc * 1024, qbase + (sl0 + u) * 4096, 0);
                 dst[u][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
             }
     };
+    // Output passes: no statistics accumulators, so the wave's whole slice of the table (QS x 4 fragments = 128
+    // registers) is loaded once per workgroup and stays resident -- no table traffic inside the tile loop.
+    constexpr bool RESIDENT = GI8 && !EM;
+    i4_t qt[RESIDENT ? QS : 1][4];
+    if constexpr (RESIDENT) {
+#pragma unroll
+        for (int sl = 0; sl < QS; sl += 2) load_pair(*reinterpret_cast<i4_t(*)[2][4]>(&qt[sl]), sl);
+    }
     if constexpr (GI8) {
         if (PREFETCH_A) load_pair(qbA, 6);
     }
@@ -358,6 +381,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
 #define PPCA_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+#elif defined(PPCA_MARKS)  // tools/devbuild.py -DPPCA_MARKS --asm: phase boundaries as comments in the ISA listing
+#define PPCA_STAMP(i) asm volatile("; PPCA_MARK " #i ::: "memory");
 #else
 #define PPCA_STAMP(i)
 #endif
@@ -366,19 +391,19 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // them -- lane 4r+q keeps mask word q of row r, lane r keeps xx_r / m_r (v_writelane drops each scalar
     // into its lane: 32 "lane == c" compare masks would overflow the SGPR file) -- so the whole wave does
     // ONE compact store per array.
-    int st_wlo = 0, st_whi = 0, st_m = 0, st_xlo = 0, st_xhi = 0;
-    auto stage_begin = [&]() { st_wlo = st_whi = st_m = st_xlo = st_xhi = 0; };
-    // One row = 14 small pieces (each well under the 64 cycles of one fp64 MFMA) so that P4 can drop one piece
-    // behind each of its MFMAs: per half h of the row, two "classify + centre" pieces (elements 2h, 2h+1) and one
-    // "file" piece (mask words, x~ pair, sums); 6 = popcount; 7..12 = the six DPP steps of the row sum, 13 = row sum
-    // into its lane.
+    int st_wlo = 0, st_whi = 0;
+    auto stage_begin = [&]() { st_wlo = st_whi = 0; };
+    // One row = 7 small pieces that P4 spreads over a k-step: per half h of the row, two "classify + centre" pieces
+    // (elements 2h, 2h+1) and one "file" piece (mask words, x~ pair, squares); 6 = the row's |x~|^2.
     // (the EM pass needs only the weighted SUM of the |x~_i|^2 -- sigma^2 and the total llk are linear in it --
-    //  so it keeps one running per-lane sum, reduced once per kernel, and skips pieces 7..13)
-    constexpr int STAGE_PIECES = EM ? 7 : 14;
+    //  so it keeps one running per-lane sum, reduced once per kernel; the output passes keep the eight per-lane
+    //  partials of a wave's rows and sum them together in stage_end)
+    constexpr int STAGE_PIECES = 7;
     double xx_run = 0.0;
+    double pxx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static_assert(EM || RPW == 8, "output passes: eight staged rows per wave (store_row_sums)");
     double pc_xt0 = 0.0, pc_xt1 = 0.0, pc_xx = 0.0;
     unsigned long long pc_b0 = 0ull, pc_b1 = 0ull;
-    int pc_m = 0;
     auto stage_piece = [&](int64_t t, int lane, auto r_tag, auto p_tag) {
         constexpr int r = decltype(r_tag)::value, P = decltype(p_tag)::value;
         const int ri = wave * RPW + r;
@@ -386,7 +411,6 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             constexpr int q = (P < 2) ? P : P - 1, e = q & 1;
             if constexpr (q == 0) {
                 pc_xx = 0.0;
-                pc_m = 0;
             }
             // Rows past n (the clamped last row again) and the tile staged behind the workgroup's last P4 (another
             // workgroup's, or none) are staged like any other: every consumer weighs them with zero or skips them.
@@ -413,31 +437,14 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 * h + 2 * lane) = d2_t{pc_xt0, pc_xt1};  // 16-byte aligned
             pc_xx += pc_xt0 * pc_xt0;
             pc_xx += pc_xt1 * pc_xt1;
-            pc_m += __popcll(pc_b0) + __popcll(pc_b1);
         } else if constexpr (P == 6) {
-            st_m = writelane<r>(st_m, pc_m);
+            if constexpr (!EM) pxx[r] = pc_xx;  // the per-sample |x~|^2: the eight rows are summed together in stage_end
             if constexpr (EM) {
                 // wave-uniform: a real row of one of THIS workgroup's tiles (32-bit compare on the scalar unit)
                 const bool mine = (int)(t - tile_begin) * B + ri < nmine;
                 const double wr = mine ? (p.w ? p.w[t * B + ri] : 1.0) : 0.0;  // (scalar load)
                 xx_run += wr * pc_xx;
             }
-        } else if constexpr (P == 7) {
-            pc_xx += dpp_f64<0xB1, 0xF>(pc_xx);   // quad_perm [1,0,3,2]
-        } else if constexpr (P == 8) {
-            pc_xx += dpp_f64<0x4E, 0xF>(pc_xx);   // quad_perm [2,3,0,1]
-        } else if constexpr (P == 9) {
-            pc_xx += dpp_f64<0x141, 0xF>(pc_xx);  // row_half_mirror
-        } else if constexpr (P == 10) {
-            pc_xx += dpp_f64<0x140, 0xF>(pc_xx);  // row_mirror
-        } else if constexpr (P == 11) {
-            pc_xx += dpp_f64<0x142, 0xA>(pc_xx);  // row_bcast15
-        } else if constexpr (P == 12) {
-            pc_xx += dpp_f64<0x143, 0xC>(pc_xx);  // row_bcast31: lane 63 = total
-        } else if constexpr (P == 13) {
-            const long long tb = __double_as_longlong(pc_xx);
-            st_xlo = writelane<r>(st_xlo, __builtin_amdgcn_readlane((int)tb, 63));
-            st_xhi = writelane<r>(st_xhi, __builtin_amdgcn_readlane((int)(tb >> 32), 63));
         }
     };
     auto stage_row = [&](int64_t t, int lane, auto r_tag) {
@@ -445,12 +452,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     };
     auto stage_end = [&](int lane, int par) {
         const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
-        const double myxx = __longlong_as_double(((long long)st_xhi << 32) | (unsigned)st_xlo);
         if (lane < 4 * RPW) Ms[par * 4 * B + wave * 4 * RPW + lane] = myw;
-        if (lane < RPW) {
-            if constexpr (!EM) xxs[wave * RPW + lane] = myxx;
-            mcnt[wave * RPW + lane] = st_m;
-        }
+        if constexpr (!EM) store_row_sums(pxx, lane, xxs + wave * RPW);
     };
     if constexpr (EM) {
         if (tile_begin < tile_end) {
@@ -536,8 +539,10 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #pragma unroll
                         for (int kc = 0; kc < 4; ++kc) mwd[rt2][kc] = Msc[(16 * rt2 + l15) * 4 + kc];
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!PREFETCH_A) load_pair(qbA, 6);
-                    load_pair(qbB, 4);
+                    if constexpr (!RESIDENT) {
+                        if (!PREFETCH_A) load_pair(qbA, 6);
+                        load_pair(qbB, 4);
+                    }
                     if (gram_wave) qs = p.qscale[16 * wave + l15];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -550,10 +555,15 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                                 af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
                         }
                     PPCA_STAMP(12)
-                    group(qbA, true);   // digits {7,6}: requested during the previous P4
-                    load_pair(qbA, 2);
-                    group(qbB, false);  // digits {5,4}
-                    load_pair(qbB, 0);
+                    if constexpr (RESIDENT) {
+                        group(qt + 6, true);
+                        group(qt + 4, false);
+                    } else {
+                        group(qbA, true);   // digits {7,6}: requested during the previous P4
+                        load_pair(qbA, 2);
+                        group(qbB, false);  // digits {5,4}
+                        load_pair(qbB, 0);
+                    }
                 }
             }
             PPCA_STAMP(13)
@@ -595,8 +605,13 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             }
             PPCA_STAMP(14)
             if constexpr (GI8) {
-                group(qbA, false);  // digits {3,2}
-                group(qbB, false);  // digits {1,0}
+                if constexpr (RESIDENT) {
+                    group(qt + 2, false);
+                    group(qt + 0, false);
+                } else {
+                    group(qbA, false);  // digits {3,2}
+                    group(qbB, false);  // digits {1,0}
+                }
                 if (gram_wave) {
 #pragma unroll
                     for (int rt2 = 0; rt2 < 2; ++rt2)
@@ -638,7 +653,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             const double *g0 = Gp + i * GS;
             const double *g1 = g0 + B * GS;
             const double wgt = (row < n) ? (p.w ? p.w[row] : 1.0) : 0.0;
-            const int m = mcnt[i];
+            // observed count of the sample: popcount of its four mask words (the padding past d is never set)
+            const int m = __popcll(Msc[i * 4]) + __popcll(Msc[i * 4 + 1]) + __popcll(Msc[i * 4 + 2]) + __popcll(Msc[i * 4 + 3]);
             double *wrow = Ws + i * WS;
             double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;  // this tile's terms
             const double sq_run = scl[wave * SQW + (PAIRS ? lane : i)];
@@ -767,12 +783,13 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 // operands of step s+1 are read from LDS before the MFMAs of step s issue (fenced: hipcc otherwise
                 // sinks the reads to their uses and waits on LDS in front of every step)
                 double bzb[2], axb[2][RT];
+                const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile + 1);
                 bzb[0] = Ws[l4 * WS + 16 * NTP + l15];
 #pragma unroll
                 for (int r = 0; r < RT; ++r) axb[0][r] = Xs[l4 * XS + DW * wave + 16 * r + l15];
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    if (s < RPW) load_row(tile + 1, s);  // unconditional (clamped rows); two rows per step measured slower
+                    if (s < RPW) load_row(trs, tile + 1, s);  // unconditional; two rows per step measured slower
                     if (s + 1 < 8) {
                         const int smp = 4 * (s + 1) + l4;
                         bzb[(s + 1) & 1] = Ws[smp * WS + 16 * NTP + l15];

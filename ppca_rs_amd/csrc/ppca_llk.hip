@@ -47,23 +47,6 @@ struct CfgL {
     static constexpr int LDS_DOUBLES = OFF_XX + 2 * B;
 };
 
-// a (lanes 0-31 | 32-63), b -> lanes 0-31: a_lo + a_hi, lanes 32-63: b_lo + b_hi (v_permlane32_swap exchanges the
-// upper half of its first operand with the lower half of its second)
-__device__ __forceinline__ double fold_halves(double a, double b) {
-    const long long ab = __double_as_longlong(a), bb = __double_as_longlong(b);
-    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ab, (unsigned)bb, false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
-    return __longlong_as_double(((long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
-}
-// rows of 16 lanes (r0 r1 r2 r3): -> rows 0, 2: a_even + a_odd, rows 1, 3: b_even + b_odd (v_permlane16_swap exchanges
-// the odd rows of its first operand with the even rows of its second)
-__device__ __forceinline__ double fold_rows(double a, double b) {
-    const long long ab = __double_as_longlong(a), bb = __double_as_longlong(b);
-    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ab, (unsigned)bb, false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
-    return __longlong_as_double(((long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
-}
-
 template <int K>
 __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
     using cfg = CfgL<K>;
@@ -180,26 +163,7 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
         });
         const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
         if (lane < 4 * RPW) Ms[(slot * B + wave * RPW) * 4 + lane] = myw;
-        // eight per-lane partials -> eight row totals: halves, then 16-lane rows, then within the rows
-        double u[4], w2[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = fold_halves(pxx[2 * i], pxx[2 * i + 1]);  // half h: row 2 i + h
-#pragma unroll
-        for (int j = 0; j < 2; ++j) w2[j] = fold_rows(u[2 * j], u[2 * j + 1]);       // 16-lane row rho: row 4 j + 2 (rho & 1) + (rho >> 1)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            double v = w2[j];
-            v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-            v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-            v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
-            v += dpp_f64<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
-            w2[j] = v;
-        }
-        if ((lane & 15) == 0) {
-            const int rho = lane >> 4, r0 = 2 * (rho & 1) + (rho >> 1);
-            xxs[slot * B + wave * RPW + r0] = w2[0];
-            xxs[slot * B + wave * RPW + 4 + r0] = w2[1];
-        }
+        store_row_sums(pxx, lane, xxs + slot * B + wave * RPW);
     };
     // ---- P2: [G | b] of the staged tile into rows slot * B .. of the exchange buffers
     auto contract_tile = [&](int lane, int slot) {
