@@ -6,13 +6,13 @@ R=/root/repo; S=$R/gpurun_out/r2f; D=$R/profiles/r02
 mkdir -p $D
 cp $S/bench_n10m.json $D/bench_n10m.json
 cp $S/kt_bench.json $D/bench_n10m_under_rocprof.json
-cp $(find $S/kt -name "*kernel_stats.csv") $D/bench_n10m_kernel_stats.csv
-cp $(find $S/pmc_fetch -name "*counter_collection.csv") $D/pmc_n10m_FETCH_SIZE_counter_collection.csv
-cp $(find $S/pmc_write -name "*counter_collection.csv") $D/pmc_n10m_WRITE_SIZE_counter_collection.csv
-cp $(find $S/pmc_mfma -name "*counter_collection.csv") $D/pmc_n1m_mfma_counter_collection.csv
+cp $(ls -t $(find $S/kt -name "*kernel_stats.csv") | head -1) $D/bench_n10m_kernel_stats.csv
+cp $(ls -t $(find $S/pmc_fetch -name "*counter_collection.csv") | head -1) $D/pmc_n10m_FETCH_SIZE_counter_collection.csv
+cp $(ls -t $(find $S/pmc_write -name "*counter_collection.csv") | head -1) $D/pmc_n10m_WRITE_SIZE_counter_collection.csv
+cp $(ls -t $(find $S/pmc_mfma -name "*counter_collection.csv") | head -1) $D/pmc_n1m_mfma_counter_collection.csv
 cp $S/bench_cfg4.json $D/bench_cfg4.json
-cp $(find $S/kt_cfg4 -name "*kernel_stats.csv") $D/bench_cfg4_kernel_stats.csv
-cp $(find $S/kt_mix -name "*kernel_stats.csv") $D/mix_cfg5_kernel_stats.csv
+cp $(ls -t $(find $S/kt_cfg4 -name "*kernel_stats.csv") | head -1) $D/bench_cfg4_kernel_stats.csv
+cp $(ls -t $(find $S/kt_mix -name "*kernel_stats.csv") | head -1) $D/mix_cfg5_kernel_stats.csv
 cp $S/mix_cfg5.log $D/mix_cfg5_time.log
 [ -f $S/passes.log ] && cp $S/passes.log $D/passes_n4m.log
 python3 - <<PY
