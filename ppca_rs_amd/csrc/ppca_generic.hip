@@ -429,13 +429,16 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
     const int64_t n0 = (int64_t)blockIdx.x * 32;
     const bool second = g.ksplit > 0 && blockIdx.z == 1;
     const int64_t kbeg = second ? g.ksplit : 0, kend = (g.ksplit > 0 && !second) ? g.ksplit : g.K;
-    gi4_t acc[2][2][GQS];
+    // Wave tile 64 rows x 16 columns x GQS slices (waves as 2 x 2 over the 128 x 32 workgroup tile): 4 A fragments
+    // + GQS B fragments read from LDS per 4 GQS MFMAs of a 64-byte K-step -- 0.375 reads per MFMA where a 32 x 32
+    // wave tile needs 0.56 (measured: the same 266 ms per iteration at config 4 either way -- LDS reads are not what
+    // holds this kernel at a quarter of the int8 MFMA rate).
+    const int wm = wave >> 1, wn = wave & 1;
+    gi4_t acc[4][GQS];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int s = 0; s < GQS; ++s) acc[a][b][s] = gi4_t{0, 0, 0, 0};
+        for (int s = 0; s < GQS; ++s) acc[a][s] = gi4_t{0, 0, 0, 0};
     gi4_t ra[NA], rb[NB];
     auto fetch = [&](int64_t k0) {
 #pragma unroll
@@ -475,39 +478,36 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
         if (more) fetch(k0 + KB);
 #pragma unroll
         for (int h = 0; h < KB / 64; ++h) {
-            gi4_t fa[2];
+            gi4_t fa[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-                fa[a] = *reinterpret_cast<const gi4_t *>(As + (buf * 128 + 32 * wave + 16 * a + l15) * RS + 64 * h + 16 * l4);
+            for (int a = 0; a < 4; ++a)
+                fa[a] = *reinterpret_cast<const gi4_t *>(As + (buf * 128 + 64 * wm + 16 * a + l15) * RS + 64 * h + 16 * l4);
 #pragma unroll
-            for (int s = 0; s < GQS; ++s)
+            for (int s = 0; s < GQS; ++s) {
+                const gi4_t fb =
+                    *reinterpret_cast<const gi4_t *>(Bs + (buf * GQS * 32 + s * 32 + 16 * wn + l15) * RS + 64 * h + 16 * l4);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const gi4_t fb =
-                        *reinterpret_cast<const gi4_t *>(Bs + (buf * GQS * 32 + s * 32 + 16 * b + l15) * RS + 64 * h + 16 * l4);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-                        acc[a][b][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb, acc[a][b][s], 0, 0, 0);
-                }
+                for (int a = 0; a < 4; ++a)
+                    acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb, acc[a][s], 0, 0, 0);
+            }
         }
         if (more) stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int64_t col = n0 + 16 * b + l15;
-        if (col >= g.N) continue;
+    {
+        const int64_t col = n0 + 16 * wn + l15;
+        if (col >= g.N) return;
         const double sc = g.scale[col];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {  // C/D map of the 16x16 integer MFMA: row = 4 (lane >> 4) + reg
-                const int64_t row = m0 + 32 * wave + 16 * a + 4 * l4 + r;
+                const int64_t row = m0 + 64 * wm + 16 * a + 4 * l4 + r;
                 if (row >= g.M) continue;
-                double v = (double)acc[a][b][GQS - 1][r];
+                double v = (double)acc[a][GQS - 1][r];
 #pragma unroll
-                for (int s = GQS - 2; s >= 0; --s) v = v * 128.0 + (double)acc[a][b][s][r];
+                for (int s = GQS - 2; s >= 0; --s) v = v * 128.0 + (double)acc[a][s][r];
                 if (second) {
                     g.out2[row * g.N + col] = v * sc;
                 } else {
