@@ -367,6 +367,10 @@ class PPCAModel:
             raise ValueError("dataset is empty")  # assert!(!dataset.is_empty()) :52
         if state_size > 64:
             raise ValueError(f"state_size {state_size} is not supported: the MI355X kernels cover state sizes up to 64")
+        if state_size < 1:
+            # (the reference accepts 0 -- an isotropic Gaussian around the mean; the same model is state_size = 1 with a
+            #  zero transform column, which every pass here reproduces exactly: G = 0, z = 0, c stays 0)
+            raise ValueError("state_size must be at least 1 (state_size = 0 is a zero transform column at state_size = 1)")
         d = dataset.output_size()
         rng = np.random.default_rng(seed)
         # DMatrix::from_vec is column-major (utils.rs:16-25)

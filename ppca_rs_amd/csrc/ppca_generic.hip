@@ -413,19 +413,22 @@ struct I8GemmArgs {
 };
 
 // KB = bytes of K per staged step (64 or 128: whole 128-byte lines per row at 128); rows padded by 16 B in LDS.
-template <int KB>
-__global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two waves per SIMD (<= 256 registers): measured 64 vs 76 ms per iteration at 1 wave, 118 ms at 3 (spills)
+// TM = rows of the workgroup tile: 128 (4 waves, two workgroups per CU) or 256 (8 waves, one workgroup per CU: the
+// B stripes -- the 8 digit planes -- are re-read by half as many row blocks).
+template <int KB, int TM = 128>
+__global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // two waves per SIMD (<= 256 registers): measured 64 vs 76 ms per iteration at 1 wave, 118 ms at 3 (spills)
+    constexpr int THREADS = 2 * TM;
     constexpr int RS = KB + 16, PR = KB / 16;           // LDS row stride, 16-byte pieces per row
-    constexpr int NA = 128 * PR / 256, NB = GQS * 32 * PR / 256;  // pieces per thread
+    constexpr int NA = TM * PR / THREADS, NB = GQS * 32 * PR / THREADS;  // pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char i8sm[];
-    unsigned char *As = i8sm;                              // [2][128][RS]
-    unsigned char *Bs = i8sm + 2 * 128 * RS;               // [2][GQS * 32][RS]
+    unsigned char *As = i8sm;                              // [2][TM][RS]
+    unsigned char *Bs = i8sm + 2 * TM * RS;                // [2][GQS * 32][RS]
     if (g.guard && *g.guard != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     // (an XCD-aware order of the tiles -- column block c pinned to XCD c % 8, row blocks of one column block side by
     //  side -- measured SLOWER, 106 vs 97 ms per iteration at N = 400 k, d = 1024, k = 64: plain 2-D order kept)
-    const int64_t m0 = (int64_t)blockIdx.y * 128;
+    const int64_t m0 = (int64_t)blockIdx.y * TM;
     const int64_t n0 = (int64_t)blockIdx.x * 32;
     const bool second = g.ksplit > 0 && blockIdx.z == 1;
     const int64_t kbeg = second ? g.ksplit : 0, kend = (g.ksplit > 0 && !second) ? g.ksplit : g.K;
@@ -443,14 +446,14 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
     auto fetch = [&](int64_t k0) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int piece = tid + 256 * u, r = piece / PR, q = piece % PR;
+            const int piece = tid + THREADS * u, r = piece / PR, q = piece % PR;
             const int64_t row = m0 + r;
             ra[u] = (row < g.M && k0 + 16 * q < kend) ? *reinterpret_cast<const gi4_t *>(g.A + row * g.lda + k0 + 16 * q)
                                                      : gi4_t{0, 0, 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int piece = tid + 256 * u, q = piece % PR, rr = piece / PR, cc = rr & 31, sl = rr >> 5;
+            const int piece = tid + THREADS * u, q = piece % PR, rr = piece / PR, cc = rr & 31, sl = rr >> 5;
             const int64_t col = n0 + cc;
             rb[u] = (col < g.N && k0 + 16 * q < kend)
                         ? *reinterpret_cast<const gi4_t *>(g.Bt + sl * g.plane + col * g.ldb + k0 + 16 * q)
@@ -460,12 +463,12 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
     auto stash = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int piece = tid + 256 * u;
-            *reinterpret_cast<gi4_t *>(As + (buf * 128 + piece / PR) * RS + 16 * (piece % PR)) = ra[u];
+            const int piece = tid + THREADS * u;
+            *reinterpret_cast<gi4_t *>(As + (buf * TM + piece / PR) * RS + 16 * (piece % PR)) = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int piece = tid + 256 * u;
+            const int piece = tid + THREADS * u;
             *reinterpret_cast<gi4_t *>(Bs + (buf * GQS * 32 + piece / PR) * RS + 16 * (piece % PR)) = rb[u];
         }
     };
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void i8gemm_kernel(I8GemmArgs g) {  // two 
             gi4_t fa[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                fa[a] = *reinterpret_cast<const gi4_t *>(As + (buf * 128 + 64 * wm + 16 * a + l15) * RS + 64 * h + 16 * l4);
+                fa[a] = *reinterpret_cast<const gi4_t *>(As + (buf * TM + 64 * wm + 16 * a + l15) * RS + 64 * h + 16 * l4);
 #pragma unroll
             for (int s = 0; s < GQS; ++s) {
                 const gi4_t fb =
@@ -1526,6 +1529,27 @@ __global__ void add_partial_kernel(double *out, int64_t ldo, const double *part,
 
 static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    static const int tm = [] {  // PPCA_I8GEMM_TM=128: the 4-wave tile everywhere (A/B runs)
+        const char *e = getenv("PPCA_I8GEMM_TM");
+        return (e && atoi(e) == 128) ? 128 : 256;
+    }();
+    // tall products (the Gram: one row per sample) take the 256-row tile
+    if (tm == 256 && g.ksplit == 0 && g.M >= 4096) {
+        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 255) / 256), 1u);
+        const size_t lds = 2 * (256 + GQS * 32) * (64 + 16);
+        static std::atomic<unsigned long long> done{0ull};
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&i8gemm_kernel<64, 256>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            done.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL((i8gemm_kernel<64, 256>), grid, dim3(512), lds, s, g);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128), g.ksplit > 0 ? 2u : 1u);
     static const int kb = [] {  // 64-byte K-steps (three workgroups per CU); PPCA_I8GEMM_KB=128: whole 128-byte lines, one per CU
         const char *e = getenv("PPCA_I8GEMM_KB");
