@@ -415,7 +415,13 @@ struct I8GemmArgs {
 // KB = bytes of K per staged step (64 or 128: whole 128-byte lines per row at 128); rows padded by 16 B in LDS.
 // TM = rows of the workgroup tile: 128 (4 waves, two workgroups per CU) or 256 (8 waves, one workgroup per CU: the
 // B stripes -- the 8 digit planes -- are re-read by half as many row blocks).
-template <int KB, int TM = 128>
+// BUF: operands through buffer descriptors (per-thread piece offsets computed once, the K position a scalar offset:
+// no vector address arithmetic in the K loop -- the pointer form spent 2.7 vector instructions per MFMA on 64-bit
+// addresses and bounds, SQ_INSTS_VALU 338 M against SQ_INSTS_MFMA 91 M per launch); needs both operands < 2 GiB.
+#ifndef I8_STAGES
+#define I8_STAGES 2  // measured at config 4: 1 -> 254.0, 2 -> 253.4, 3 -> 253.2, 4 -> 262.4 ms (spills)
+#endif
+template <int KB, int TM = 128, bool BUF = true>
 __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // two waves per SIMD (<= 256 registers): measured 64 vs 76 ms per iteration at 1 wave, 118 ms at 3 (spills)
     constexpr int THREADS = 2 * TM;
     constexpr int RS = KB + 16, PR = KB / 16;           // LDS row stride, 16-byte pieces per row
@@ -442,43 +448,72 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int s = 0; s < GQS; ++s) acc[a][s] = gi4_t{0, 0, 0, 0};
-    gi4_t ra[NA], rb[NB];
-    auto fetch = [&](int64_t k0) {
+    constexpr int ST = BUF ? I8_STAGES : 1;  // K-steps in flight in registers (buffer form: over-fetching past K is harmless)
+    gi4_t ra[ST][NA], rb[ST][NB];
+    // rows / columns outside the product read as zeros: their offset lies past the descriptor's extent
+    unsigned aoff[NA], boff[NB];
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(g.A), 0, BUF ? (int)(g.M * g.lda) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<signed char *>(g.Bt), 0, BUF ? (int)(GQS * g.plane) : 0, 0x00020000);
+    if constexpr (BUF) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int piece = tid + THREADS * u, r = piece / PR, q = piece % PR;
             const int64_t row = m0 + r;
-            ra[u] = (row < g.M && k0 + 16 * q < kend) ? *reinterpret_cast<const gi4_t *>(g.A + row * g.lda + k0 + 16 * q)
+            aoff[u] = row < g.M ? (unsigned)(row * g.lda + 16 * q) : 0x80000000u;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int piece = tid + THREADS * u, q = piece % PR, rr = piece / PR, cc = rr & 31, sl = rr >> 5;
+            const int64_t col = n0 + cc;
+            boff[u] = col < g.N ? (unsigned)(sl * g.plane + col * g.ldb + 16 * q) : 0x80000000u;
+        }
+    }
+    auto fetch = [&](int64_t k0, int st) {
+        if constexpr (BUF) {  // K is a whole number of KB-byte steps (rows padded to 64 bytes)
+            typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)aoff[u], (int)k0, 0);
+                ra[st][u] = gi4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)boff[u], (int)k0, 0);
+                rb[st][u] = gi4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int piece = tid + THREADS * u, r = piece / PR, q = piece % PR;
+            const int64_t row = m0 + r;
+            ra[st][u] = (row < g.M && k0 + 16 * q < kend) ? *reinterpret_cast<const gi4_t *>(g.A + row * g.lda + k0 + 16 * q)
                                                      : gi4_t{0, 0, 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int piece = tid + THREADS * u, q = piece % PR, rr = piece / PR, cc = rr & 31, sl = rr >> 5;
             const int64_t col = n0 + cc;
-            rb[u] = (col < g.N && k0 + 16 * q < kend)
+            rb[st][u] = (col < g.N && k0 + 16 * q < kend)
                         ? *reinterpret_cast<const gi4_t *>(g.Bt + sl * g.plane + col * g.ldb + k0 + 16 * q)
                         : gi4_t{0, 0, 0, 0};
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int st) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int piece = tid + THREADS * u;
-            *reinterpret_cast<gi4_t *>(As + (buf * TM + piece / PR) * RS + 16 * (piece % PR)) = ra[u];
+            *reinterpret_cast<gi4_t *>(As + (buf * TM + piece / PR) * RS + 16 * (piece % PR)) = ra[st][u];
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int piece = tid + THREADS * u;
-            *reinterpret_cast<gi4_t *>(Bs + (buf * GQS * 32 + piece / PR) * RS + 16 * (piece % PR)) = rb[u];
+            *reinterpret_cast<gi4_t *>(Bs + (buf * GQS * 32 + piece / PR) * RS + 16 * (piece % PR)) = rb[st][u];
         }
     };
-    fetch(kbeg);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (int64_t k0 = kbeg; k0 < kend; k0 += KB) {
-        const bool more = k0 + KB < kend;
-        if (more) fetch(k0 + KB);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < KB / 64; ++h) {
             gi4_t fa[4];
@@ -494,9 +529,42 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
                     acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb, acc[a][s], 0, 0, 0);
             }
         }
-        if (more) stash(buf ^ 1);
+    };
+    if constexpr (BUF) {
+        // ST K-steps travel in registers while one is contracted out of LDS: a step is requested ST iterations (ST x
+        // ~1 k cycles of MFMAs per SIMD) before it is staged.  (The MFMA pipe is 30 % busy in this kernel by
+        // SQ_VALU_MFMA_BUSY_CYCLES; a deeper pipeline did not change that: memory latency is not what it waits for.)
+        const int nsteps = (int)((kend - kbeg) / KB);
+#pragma unroll
+        for (int j = 0; j < ST; ++j) fetch(kbeg + (int64_t)j * KB, j);
+        stash(0, 0);
+        fetch(kbeg + (int64_t)ST * KB, 0);
         __syncthreads();
-        buf ^= 1;
+        for (int i = 0; i < nsteps; i += ST) {
+#pragma unroll
+            for (int j = 0; j < ST; ++j) {
+                if (i + j < nsteps) {  // (uniform)
+                    const int buf = (i + j) & 1;
+                    compute(buf);
+                    stash(buf ^ 1, (j + 1) % ST);                                       // step i + j + 1
+                    fetch(kbeg + (int64_t)(i + j + 1 + ST) * KB, (j + 1) % ST);        // step i + j + 1 + ST
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        fetch(kbeg, 0);
+        stash(0, 0);
+        __syncthreads();
+        int buf = 0;
+        for (int64_t k0 = kbeg; k0 < kend; k0 += KB) {
+            const bool more = k0 + KB < kend;
+            if (more) fetch(k0 + KB, 0);
+            compute(buf);
+            if (more) stash(buf ^ 1, 0);
+            __syncthreads();
+            buf ^= 1;
+        }
     }
     {
         const int64_t col = n0 + 16 * wn + l15;
@@ -1527,51 +1595,45 @@ __global__ void add_partial_kernel(double *out, int64_t ldo, const double *part,
     out[r * ldo + c] += part[idx];
 }
 
+template <int TM, bool BUF>
+static hipError_t launch_i8gemm_t(const I8GemmArgs &g, dim3 grid, hipStream_t s) {
+    const size_t lds = 2 * (TM + GQS * 32) * (64 + 16);
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (lds > 65536 && !(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&i8gemm_kernel<64, TM, BUF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((i8gemm_kernel<64, TM, BUF>), grid, dim3(2 * TM), lds, s, g);
+    return hipGetLastError();
+}
+
 static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     static const int tm = [] {  // PPCA_I8GEMM_TM=128: the 4-wave tile everywhere (A/B runs)
         const char *e = getenv("PPCA_I8GEMM_TM");
         return (e && atoi(e) == 128) ? 128 : 256;
     }();
-    // tall products (the Gram: one row per sample) take the 256-row tile
-    if (tm == 256 && g.ksplit == 0 && g.M >= 4096) {
-        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 255) / 256), 1u);
-        const size_t lds = 2 * (256 + GQS * 32) * (64 + 16);
-        static std::atomic<unsigned long long> done{0ull};
-        int dev = 0;
-        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(done.load(std::memory_order_acquire) & bit)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&i8gemm_kernel<64, 256>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            done.fetch_or(bit, std::memory_order_release);
-        }
-        hipLaunchKernelGGL((i8gemm_kernel<64, 256>), grid, dim3(512), lds, s, g);
-        return hipGetLastError();
-    }
-    dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128), g.ksplit > 0 ? 2u : 1u);
-    static const int kb = [] {  // 64-byte K-steps (three workgroups per CU); PPCA_I8GEMM_KB=128: whole 128-byte lines, one per CU
-        const char *e = getenv("PPCA_I8GEMM_KB");
-        return (e && atoi(e) == 128) ? 128 : 64;
+    static const bool nobuf = [] {  // PPCA_I8GEMM_PTR=1: operands by pointer arithmetic (A/B runs; the form for >= 2 GiB)
+        const char *e = getenv("PPCA_I8GEMM_PTR");
+        return e && atoi(e) == 1;
     }();
-    if (kb == 64) {
-        const size_t lds = 2 * (128 + GQS * 32) * (64 + 16);
-        hipLaunchKernelGGL((i8gemm_kernel<64>), grid, dim3(256), lds, s, g);
+    // K is walked in 64-byte steps; both callers pad their rows to that
+    const bool buf = !nobuf && g.K % 64 == 0 && (g.ksplit % 64) == 0 && g.M * g.lda < (int64_t(1) << 31) &&
+                     GQS * g.plane < (int64_t(1) << 31);
+    hipError_t e;
+    if (tm == 256 && g.ksplit == 0 && g.M >= 4096) {  // tall products (the Gram: one row per sample): 256-row tile
+        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 255) / 256), 1u);
+        e = buf ? launch_i8gemm_t<256, true>(g, grid, s) : launch_i8gemm_t<256, false>(g, grid, s);
     } else {
-        const size_t lds = 2 * (128 + GQS * 32) * (128 + 16);
-        static std::atomic<unsigned long long> done{0ull};
-        int dev = 0;
-        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(done.load(std::memory_order_acquire) & bit)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&i8gemm_kernel<128>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            done.fetch_or(bit, std::memory_order_release);
-        }
-        hipLaunchKernelGGL((i8gemm_kernel<128>), grid, dim3(256), lds, s, g);
+        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128), g.ksplit > 0 ? 2u : 1u);
+        e = buf ? launch_i8gemm_t<128, true>(g, grid, s) : launch_i8gemm_t<128, false>(g, grid, s);
     }
+    if (e != hipSuccess) return e;
     if (g.ksplit > 0) {
         const int64_t tot = g.M * g.N;
         hipLaunchKernelGGL(add_partial_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, g.out, g.ldo, g.out2, g.M, g.N,
