@@ -653,8 +653,9 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
                 t[12] / tiles, t[13] / tiles, t[14] / tiles, t[1] / tiles);
         fprintf(stderr, "[ppca phase cycles/tile] P1 %.0f  P2 %.0f  P3 %.0f (wave 0: factor %.0f, solve %.0f, columns %.0f, scalars %.0f, barrier %.0f)  P4 %.0f (cross+barrier %.0f, mask+staging %.0f, barrier %.0f)  (tiles/WG %.1f)\n",
                 (t[0] + t[5]) / tiles, (t[1] + t[12] + t[13] + t[14]) / tiles, (t[2] + t[8] + t[9] + t[10] + t[11]) / tiles, t[8] / tiles, t[9] / tiles,
-                t[10] / tiles, t[11] / tiles, t[2] / tiles, (t[3] + t[4] + t[6] + t[7]) / tiles,
+                t[10] / tiles, t[11] / tiles, t[2] / tiles, (t[3] + t[4] + t[5] + t[6] + t[7] + t[15]) / tiles,
                 (t[4] + t[6]) / tiles, t[7] / tiles, t[3] / tiles, tiles);
+        fprintf(stderr, "[ppca P4b int8 cycles/tile] staging %.0f  digitise %.0f  contraction + barriers + stores %.0f\n", t[5] / tiles, t[15] / tiles, t[7] / tiles);
     }
 #endif
     return PPCA_OK;

@@ -34,7 +34,15 @@ struct Cfg {
     // once-per-tile values in scratch and reloads them with an exposed vmcnt(0)):
     // sq[NW <= 8 waves][B] | dev[B] | llk[B] | sumw[B] | nonempty[B] | det mantissa[B] | det exponent[B]
     static constexpr int OFF_L = OFF_S + 2 * B;
-    static constexpr int LDS_DOUBLES = OFF_L + 22 * B;  // (sq has two slots per solver sample when the waves pair lanes)
+    // int8 form of the mask-side statistics contraction (pass_kernel, P4I8): the second K-half of b moves out of the
+    // second [G | b] buffer (which then holds a tile's digit planes) into P1 [B][K + 1]; column exponents of the
+    // group's two tiles (2 x 16 NTM ints) and a flag word follow.  The per-dimension sample masks of a group
+    // (256 x u64) live in the part of the L region that only the 8-wave variant uses.
+    static constexpr int OFF_P1 = OFF_L + 22 * B;  // (sq has two slots per solver sample when the waves pair lanes)
+    static constexpr int OFF_E = OFF_P1 + B * (K + 1);
+    static constexpr int LDS_DOUBLES = OFF_E + 16 * NTM + 2;
+    static constexpr int OFF_MB = OFF_L + 14 * B;  // 4 waves use L[0 .. 14 B); 256 u64 fit in [14 B, 22 B)
+    static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget");
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -129,6 +137,15 @@ __device__ __forceinline__ void writelane_mask(int &dlo, int &dhi, unsigned long
         : "+v"(dlo), "+v"(dhi)
         : "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "n"(LANE));
 }
+// writelane_mask + the lane's own bit of the mask shifted into `bits` (bits = 2 bits + bit: v_addc with the mask as the
+// carry-in), so that after a wave's eight staged rows `bits` holds the lane's dimension over those samples.
+template <int LANE>
+__device__ __forceinline__ void file_mask(int &dlo, int &dhi, int &bits, unsigned long long m) {
+    asm("s_nop 1\n\tv_writelane_b32 %0, %3, %5\n\tv_writelane_b32 %1, %4, %5\n\tv_addc_co_u32_e64 %2, vcc, %2, %2, %6"
+        : "+v"(dlo), "+v"(dhi), "+v"(bits)
+        : "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "n"(LANE), "s"(m)
+        : "vcc");
+}
 // mask bit of the lane ? v : 0.0 with the wave mask taken straight from its SGPR pair (a C++ select on
 // (mask >> lane) & 1 would rebuild the predicate with vector shifts).
 __device__ __forceinline__ double keep_if(double v, unsigned long long mask) {
@@ -154,6 +171,24 @@ __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
 // ------------------------------------------------------------------ int8-sliced Gram operand (see ppca_kernels.hip)
 constexpr int QS = 8;
 typedef int i4_t __attribute__((ext_vector_type(4)));
+
+// Seven independent v_mfma_i32_16x16x64_i8 (one A operand, seven B operands, C = 0) with the results in VGPRs: the
+// builtin's results land in accumulation registers, and under this kernel's register pressure all seven shared one
+// quad -- every MFMA waited for the previous result to be copied out.  The trailing s_nops cover the read-after-MFMA
+// wait states of the last result (the compiler does not see inside the statement).
+__device__ __forceinline__ void mfma_i8_x7(const i4_t &a, const i4_t (&b)[7], i4_t (&d)[7]) {
+    asm volatile(
+        "v_mfma_i32_16x16x64_i8 %0, %7, %8, 0\n\t"
+        "v_mfma_i32_16x16x64_i8 %1, %7, %9, 0\n\t"
+        "v_mfma_i32_16x16x64_i8 %2, %7, %10, 0\n\t"
+        "v_mfma_i32_16x16x64_i8 %3, %7, %11, 0\n\t"
+        "v_mfma_i32_16x16x64_i8 %4, %7, %12, 0\n\t"
+        "v_mfma_i32_16x16x64_i8 %5, %7, %13, 0\n\t"
+        "v_mfma_i32_16x16x64_i8 %6, %7, %14, 0\n\t"
+        "s_nop 7"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6])
+        : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]));
+}
 
 template <int K>
 constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }

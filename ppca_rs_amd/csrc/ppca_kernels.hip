@@ -168,6 +168,9 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
 // GATHER: the pass honours PassArgs::rows (sample i = physical row rows[i]); the fp64-Gram instantiations always do
 // (they are the fallback of both forms), the tuned int8 instantiation only as its own variant, so that the
 // un-gathered hot kernel carries no trace of it.
+#ifndef PPCA_P4_INT8
+#define PPCA_P4_INT8 0
+#endif
 template <int K, bool EM, int NW, bool GI8, bool GATHER = false>
 __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     using cfg = Cfg<K>;
@@ -189,6 +192,20 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     constexpr int SMALL_COLS = K + 1 - PADS;
     constexpr bool SPLIT = EM && NW == 4 && SMALL_COLS > 0 && SMALL_COLS <= 4 && PADS > 0;
     constexpr int NTMB = SPLIT ? NTP : NTM;  // big (16-column) mask-side tiles
+    // P4I8: the mask-side statistics contraction S, U, totals += Mask^T [wP | wz | w] on the int8 MFMA, two tiles
+    // (64 samples = one full K depth) at a time: see P4b below.
+    // Built and parity-green (tools/fuzz_gpu.py: 3e-13), measured at 72.7 vs 76.0 EM it/s for the fp64 form, so it is
+    // compiled in only with -DPPCA_P4_INT8=1: its 1.1 k cycles of int8 MFMAs per tile replace 8.8 k of fp64 MFMAs,
+    // but staging (2.5 k), digit cutting (3.0 k) and the fold with its barriers (6.9 k) no longer run in the shadow of
+    // anything (phase timing, N = 2 M) -- 12.4 k against the fp64 form's 12.0 k for the same work.
+    constexpr bool P4I8 = EM && NW == 4 && GI8 && (PPCA_P4_INT8 != 0);
+    constexpr int NC = KP + K + 1;         // statistic columns [wP | wz | w]
+    constexpr int NCT = (NC + 15) / 16;    // 16-column tiles of them (<= NTM)
+    constexpr int NCOL = 16 * NCT;
+    constexpr int QW = 7;                  // signed 8-bit digits of a 56-bit fixed-point form
+    constexpr int QHEAD = 3;               // binary orders kept free above the first tile's column maximum
+    static_assert(!P4I8 || (NCT <= NTM && QW * 2 * NCOL * 16 <= B * GS * 8 && (NCOL / 2) <= 64),
+                  "digit planes of a tile fit one [G | b] buffer; one wave digitises NCOL / 2 items");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(!GI8 || (NW == 4 && NTP <= 4), "int8 Gram: one wave per packed-column tile");
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -392,7 +409,11 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // into its lane: 32 "lane == c" compare masks would overflow the SGPR file) -- so the whole wave does
     // ONE compact store per array.
     int st_wlo = 0, st_whi = 0;
-    auto stage_begin = [&]() { st_wlo = st_whi = 0; };
+    int st_mb[4] = {0, 0, 0, 0};  // P4I8: this lane's four dims over the wave's eight staged samples (row r at bit 7 - r)
+    auto stage_begin = [&]() {
+        st_wlo = st_whi = 0;
+        st_mb[0] = st_mb[1] = st_mb[2] = st_mb[3] = 0;
+    };
     // One row = 7 small pieces that P4 spreads over a k-step: per half h of the row, two "classify + centre" pieces
     // (elements 2h, 2h+1) and one "file" piece (mask words, x~ pair, squares); 6 = the row's |x~|^2.
     // (the EM pass needs only the weighted SUM of the |x~_i|^2 -- sigma^2 and the total llk are linear in it --
@@ -431,8 +452,13 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             // mask word 2 h + e of the row = the ballot of element 2 h + e (bit l <-> dim 128 h + 2 l + e); the
             // readers index it that way (P2: any order of a sum, qprep lays the table out to match; P4b / output
             // pass: word by the parity of the dimension)
-            writelane_mask<4 * r + 2 * h>(st_wlo, st_whi, pc_b0);
-            writelane_mask<4 * r + 2 * h + 1>(st_wlo, st_whi, pc_b1);
+            if constexpr (P4I8) {
+                file_mask<4 * r + 2 * h>(st_wlo, st_whi, st_mb[2 * h], pc_b0);
+                file_mask<4 * r + 2 * h + 1>(st_wlo, st_whi, st_mb[2 * h + 1], pc_b1);
+            } else {
+                writelane_mask<4 * r + 2 * h>(st_wlo, st_whi, pc_b0);
+                writelane_mask<4 * r + 2 * h + 1>(st_wlo, st_whi, pc_b1);
+            }
             typedef double d2_t __attribute__((ext_vector_type(2)));
             *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 * h + 2 * lane) = d2_t{pc_xt0, pc_xt1};  // 16-byte aligned
             pc_xx += pc_xt0 * pc_xt0;
@@ -454,6 +480,14 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
         const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
         if (lane < 4 * RPW) Ms[par * 4 * B + wave * 4 * RPW + lane] = myw;
         if constexpr (!EM) store_row_sums(pxx, lane, xxs + wave * RPW);
+        if constexpr (P4I8) {
+            // sample masks per dimension for the int8 contraction: byte (4 par + wave) of dimension j's 64-bit word =
+            // its observed flags over this wave's eight samples of the group's tile `par`
+            unsigned char *mbb = reinterpret_cast<unsigned char *>(sm + cfg::OFF_MB);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                mbb[(128 * (q >> 1) + 2 * lane + (q & 1)) * 8 + 4 * par + wave] = (unsigned char)st_mb[q];
+        }
     };
     if constexpr (EM) {
         if (tile_begin < tile_end) {
@@ -624,7 +658,15 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             // G = (p0 [+ p2]) + (p1 [+ p3]); the bracketed terms are added in place by their owner
             double *g = Gp + (kq & 1) * B * GS;
             constexpr int T0 = GI8 ? NTP : 0;  // int8 Gram: only the b tile comes from the fp64 accumulators
-            if (kq < 2) {
+            if constexpr (P4I8) {
+                // (the second buffer holds digit planes: the second K-half of b goes to its own compact array)
+                double *p1 = sm + cfg::OFF_P1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kq == 0) g[(16 * rt + l4 + 4 * r) * GS + 16 * NTP + l15] = acc[NTP][r];
+                    else if (l15 < K + 1) p1[(16 * rt + l4 + 4 * r) * (K + 1) + l15] = acc[NTP][r];
+                }
+            } else if (kq < 2) {
 #pragma unroll
                 for (int t = T0; t < NTM; ++t)
 #pragma unroll
@@ -664,7 +706,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             post.factor([&](int e) { return GI8 ? g0[e] : g0[e] + g1[e]; }, s2, pm, pe);
             PPCA_STAMP(8)
             double z[K], quad, zz;
-            post.solve([&](int a) { return g0[16 * NTP + a] + g1[16 * NTP + a]; }, z, quad, zz);
+            const double *p1row = sm + cfg::OFF_P1 + i * (K + 1);
+            post.solve([&](int a) { return g0[16 * NTP + a] + (P4I8 ? p1row[a] : g1[16 * NTP + a]); }, z, quad, zz);
             PPCA_STAMP(9)
             double trpart = 0.0;
             // llk / llks / states / smooth / extrapolate need z only: the posterior covariance (the M^-1 columns)
@@ -713,7 +756,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #pragma unroll
                     for (int a = 0; a < K; ++a) zrow[a] = wgt * z[a];
                     zrow[K] = wgt;
-                    if constexpr (SPLIT) {  // the leading [w z | w] columns again, in the padding behind vech(P)
+                    if constexpr (SPLIT && !P4I8) {  // the leading [w z | w] columns again, in the padding behind vech(P)
 #pragma unroll
                         for (int a = 0; a < PADS; ++a) wrow[KP + a] = (a < K) ? wgt * z[a] : wgt;
                     }
@@ -806,63 +849,232 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             PPCA_STAMP(4)
             // (b) S/U/totals += Mask^T [wP | wz | w], with the staging (P1) of the next tile's rows between the MFMAs
             stage_begin();
-            if constexpr (GI8) {
+            if constexpr (GI8 && !P4I8) {
                 // the next tile's first digit pair (the table is tile-independent); holding the second pair
                 // across P4 as well spills 73 registers
                 if (PREFETCH_A) load_pair(qbA, 6);
             }
-            // mask operand of dims DW wave + 16 r + l15: word 2 (dim / 128) + parity, bit (dim % 128) / 2
-            const int mword = 2 * ((DW * wave) >> 7) + (l15 & 1);
-            unsigned long long mwc = Msc[l4 * 4 + mword];
-            double bwc[NTMB], bsc = 0.0;
+            if constexpr (P4I8) {
+
+                // S, U, totals += Mask^T [wP | wz | w] on the int8 MFMA.  The mask operand is exactly 0 / 1; the rows of
+                // [wP | wz | w] are cut into QW signed 8-bit digits of a per-column fixed-point form and contracted
+                // with exact integer accumulation over a GROUP of two tiles (64 samples = the full K depth of
+                // v_mfma_i32_16x16x64_i8); the 7 integer sums of an entry are recombined exactly (three digits per
+                // i32) and folded into the fp64 accumulators once per group.  Scales: the group's scale of a column is
+                // 2^QHEAD above the first tile's column maximum; the second tile uses it when its own maximum fits
+                // (the common case), otherwise the two tiles are contracted one after the other, each with its own
+                // scale (same code, the other half's mask bytes zeroed).  A non-finite column poisons its scale, so
+                // NaN / inf reach the statistics as they would through fp64.
+                // fp64 form: 16 + 4 MFMAs of 64 cycles per 4 samples and wave; here 7 x 20 of 16 cycles per 64.
+                const int rel = (int)(tile - tile_begin);
+                const int half = rel & 1;
+                // digit planes of the group's first tile: second [G | b] buffer; of its second tile: the first buffer
+                // (free once that tile's P3 has read its Gram).  Kept as offsets from ONE LDS base: a select between two
+                // pointers would lose the address space (flat loads).
+                unsigned char *wq_base = reinterpret_cast<unsigned char *>(Gp);
+                constexpr int WQ_FIRST = B * GS * 8;  // byte offset of the first tile's planes
+                int *Ex = reinterpret_cast<int *>(sm + cfg::OFF_E);  // [2][NCOL] column exponents (group / second tile), flag
+                int *viol = Ex + 2 * NCOL;
+                {
+                    // ---- digitise this tile: item = (column c, 16-sample chunk), NCOL / 2 items per wave
+                    const bool active = lane < NCOL / 2;
+                    const int it = (NCOL / 2) * wave + (active ? lane : 0);
+                    const int c = it >> 1, chunk = it & 1;
+                    const bool cvalid = c < NC;
+                    const int src = cvalid ? (c < KP ? c : 16 * NTP + (c - KP)) : 0;
+                    double wv[16];
 #pragma unroll
-            for (int t = 0; t < NTMB; ++t) bwc[t] = Ws[l4 * WS + 16 * t + l15];
-            if constexpr (SPLIT) bsc = Ws[l4 * WS + 16 * NTP + PADS + (lane & 3)];
-            // One staging piece follows each MFMA.  Measured (tools/ubench_shadow.hip): v_mfma_f64 holds the
-            // SIMD's VALU port for its 64 cycles -- no VALU instruction of this wave overlaps it, only LDS,
-            // SALU and memory instructions do -- so this interleave hides the staging's LDS writes and the
-            // row-load latency, not its ALU work.  The B operands of step s+1 are read from LDS during step s.
-            // B operand of the 4x4x4 blocks: lane = 16 k + 4 block + j -> W[sample 4 s + k][column j of the group];
-            // its A operand (lane = 16 k + 4 block + i -> dim 4 block + i, sample k) is the SAME register as the
-            // 16x16x4 tiles' (row = lane % 16, k = lane / 16): no extra mask expansion.
-            static_for<8>([&](auto s_tag) {
-                constexpr int s = decltype(s_tag)::value;
-                unsigned long long mwn = 0ull;
-                double bwn[NTMB], bsn = 0.0;
-                constexpr int PER_R = NTMB + (SPLIT ? 1 : 0);  // MFMAs per row tile and k-step
-                constexpr int SLOTS = RT * PER_R;
-                static_for<SLOTS>([&](auto i_tag) {
-                    constexpr int i = decltype(i_tag)::value, r = i / PER_R, t = i % PER_R;
-                    // am = bit ? 1.0 : 0.0 in two ops: sign-extended 1-bit field (0 / -1) & high word of 1.0
-                    const int sh = (((DW * wave) & 127) >> 1) + 8 * r;
-                    const int am_hi = __builtin_amdgcn_sbfe((int)(unsigned)(mwc >> (sh & 32)), (sh & 31) + (l15 >> 1), 1) & 0x3FF00000;
-                    const double am = __hiloint2double(am_hi, 0);
-                    if constexpr (t < NTMB) {
-                        accM[r][t] = mfma(am, bwc[t], accM[r][t]);
+                    for (int j = 0; j < 16; ++j) wv[j] = Ws[(16 * chunk + j) * WS + src];
+                    double m = 0.0;
+                    bool fin = true;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        wv[j] = cvalid ? wv[j] : 0.0;
+                        const double av = __builtin_fabs(wv[j]);
+                        fin = fin && (av < __builtin_inf());
+                        m = __builtin_fmax(m, av);
+                    }
+                    // the other chunk of the column sits in the neighbouring lane
+                    m = __builtin_fmax(m, dpp_f64<0xB1, 0xF>(m));
+                    const int finw = __builtin_amdgcn_update_dpp(0, fin ? 1 : 0, 0xB1, 0xF, 0xF, true);
+                    fin = fin && finw != 0;
+                    int e = m > 0.0 ? __builtin_amdgcn_frexp_exp(m) : -900;  // |w| < 2^e
+                    e = e < -900 ? -900 : e;
+                    int E;
+                    if (half == 0) {
+                        E = fin ? e + QHEAD : 100000;
+                        if (active && chunk == 0) {
+                            Ex[c] = E;
+                            Ex[NCOL + c] = E;
+                        }
+                        if (tid == 0) *viol = 0;
                     } else {
-                        accS[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, bsc, accS[r], 0, 0, 0);
+                        const int Eg = Ex[c];
+                        const bool over = !fin || e > Eg;  // (a poisoned group scale stays poisoned)
+                        E = (Eg > 5000) ? Eg : (fin ? (e > Eg ? e : Eg) : 100000);
+                        if (active && chunk == 0) Ex[NCOL + c] = E;
+                        if (active && over && Eg <= 5000) *viol = 1;
                     }
-                    if constexpr (s < RPW) {  // the row's pieces spread evenly over the step's MFMAs
-                        constexpr int P0 = i * STAGE_PIECES / SLOTS, P1 = (i + 1) * STAGE_PIECES / SLOTS;
-                        static_for<P1 - P0>([&](auto o_tag) {
-                            stage_piece(tile + 1, lane, s_tag, std::integral_constant<int, P0 + decltype(o_tag)::value>{});
-                        });
-                    }
-                    if constexpr (i == SLOTS * 3 / 4 && s + 1 < 8) {
-                        const int smp = 4 * (s + 1) + l4;
-                        mwn = Msc[smp * 4 + mword];
+                    const double qsc = __builtin_ldexp(1.0, 54 - (E > 5000 ? 0 : E));
+                    unsigned wlo[16], whi[16];
 #pragma unroll
-                        for (int tt = 0; tt < NTMB; ++tt) bwn[tt] = Ws[smp * WS + 16 * tt + l15];
-                        if constexpr (SPLIT) bsn = Ws[smp * WS + 16 * NTP + PADS + (lane & 3)];
+                    for (int j = 0; j < 16; ++j) {
+                        // I = rint(w 2^(54 - E)), |I| < 2^54, as two's complement (hi, lo); + 0x80 per byte with carries,
+                        // then ^ 0x80 per byte: bytes 0..6 are the signed digits, I = sum d_k 256^k exactly
+                        const double xr = __builtin_rint(wv[j] * qsc);
+                        const double xh = __builtin_floor(xr * 2.3283064365386963e-10);  // 2^-32
+                        const int hi = (int)xh;
+                        const unsigned lo = (unsigned)__builtin_fma(xh, -4294967296.0, xr);
+                        unsigned long long u = (((unsigned long long)(unsigned)hi << 32) | lo) + 0x0080808080808080ull;
+                        u ^= 0x0080808080808080ull;
+                        wlo[j] = (unsigned)u;
+                        whi[j] = (unsigned)(u >> 32);
+                    }
+                    // 4 x 4 byte transposes: plane k of samples 4 g .. 4 g + 3 = bytes k of their four words
+                    unsigned pl[QW][4];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        auto tr4 = [&](const unsigned *w, unsigned *o0, unsigned *o1, unsigned *o2, unsigned *o3) {
+                            const unsigned t0 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), t1 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
+                            const unsigned u0 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), u1 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
+                            *o0 = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+                            *o1 = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+                            *o2 = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+                            if (o3) *o3 = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+                        };
+                        tr4(wlo + 4 * g4, &pl[0][g4], &pl[1][g4], &pl[2][g4], &pl[3][g4]);
+                        tr4(whi + 4 * g4, &pl[4][g4], &pl[5][g4], &pl[6][g4], nullptr);
+                    }
+                    if (active) {
+                        unsigned char *wq = wq_base + (half == 0 ? WQ_FIRST : 0);
+#pragma unroll
+                        for (int sl = 0; sl < QW; ++sl)
+                            *reinterpret_cast<i4_t *>(wq + ((sl * 2 + chunk) * NCOL + c) * 16) =
+                                i4_t{(int)pl[sl][0], (int)pl[sl][1], (int)pl[sl][2], (int)pl[sl][3]};
+                    }
+                }
+                PPCA_STAMP(15)
+                // staging (P1) of the next tile: its rows, requested during P4a, have had the digit work to arrive; the
+                // row registers are dead before the contraction starts (the mask words / sample masks gathered here
+                // are stored at the end, after the contraction has read the current ones)
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<RPW>([&](auto r_tag) { stage_row(tile + 1, lane, r_tag); });
+                __builtin_amdgcn_sched_barrier(0);
+                PPCA_STAMP(5)
+                const bool two = half == 1;
+                if (two || tile + 1 == tile_end) {  // (uniform) the group is complete
+                    __syncthreads();                // digit planes, exponents, flag
+                    const bool split = two && *viol != 0;
+                    const unsigned long long *Mb = reinterpret_cast<const unsigned long long *>(sm + cfg::OFF_MB);
+                    const int npass = split ? 2 : 1;
+#pragma unroll 1
+                    for (int pass = 0; pass < npass; ++pass) {  // (one copy of the code: 140 MFMAs + their folds)
+                        const int sel = split ? pass : -1;      // < 0: both tiles under the group scale; 0 / 1: one tile
+                        i4_t af[RT];
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) {
+                            const unsigned long long mbits = Mb[DW * wave + 16 * r + l15];
+                            unsigned f = (unsigned)(mbits >> (16 * l4)) & 0xFFFFu;
+                            const int lh = l4 >> 1;
+                            const bool keep = sel < 0 ? (two || lh == 0) : lh == sel;
+                            f = keep ? f : 0u;
+                            // rows were shifted in first-to-last: row r of a byte at bit 7 - r; after the bit reversal
+                            // samples 0..7 of the chunk sit at bits 24..31, samples 8..15 at bits 16..23, ascending
+                            const unsigned g = __builtin_bitreverse32(f);
+                            af[r][0] = (int)((((g >> 24) & 0xFu) * 0x00204081u) & 0x01010101u);
+                            af[r][1] = (int)((((g >> 28) & 0xFu) * 0x00204081u) & 0x01010101u);
+                            af[r][2] = (int)((((g >> 16) & 0xFu) * 0x00204081u) & 0x01010101u);
+                            af[r][3] = (int)((((g >> 20) & 0xFu) * 0x00204081u) & 0x01010101u);
+                        }
+                        const unsigned char *wq = wq_base + ((l4 >> 1) == 0 ? WQ_FIRST : 0);
+                        const int *Eh = Ex + (sel == 1 ? NCOL : 0);
+#pragma unroll
+                        for (int t = 0; t < NCT; ++t) {
+                            const int c = 16 * t + l15;
+                            const int E = Eh[c];
+                            // 2^(E - 54), or a NaN for a poisoned column (built from bits: as an arithmetic select the
+                            // compiler would carry the NaN case through every accumulator update)
+                            const double fsc = __hiloint2double(E > 5000 ? 0x7FF80000 : (E + 969) << 20, 0);
+                            i4_t bq[QW];
+#pragma unroll
+                            for (int sl = 0; sl < QW; ++sl)
+                                bq[sl] = *reinterpret_cast<const i4_t *>(wq + ((sl * 2 + (l4 & 1)) * NCOL + c) * 16);
+                            static_assert(QW == 7 && RT % 2 == 0, "mfma_i8_x7, row tiles in pairs");
+#pragma unroll
+                            for (int r2 = 0; r2 < RT; r2 += 2) {
+                                // two row tiles at a time: 14 MFMAs in flight, then eight independent fold chains
+                                i4_t ia[2][QW];
+                                mfma_i8_x7(af[r2], bq, ia[0]);
+                                mfma_i8_x7(af[r2 + 1], bq, ia[1]);
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {  // D row = 4 l4 + q (dim 16 r + 4 l4 + q), column l15
+                                        const int i1 = (((ia[u][2][q] << 8) + ia[u][1][q]) << 8) + ia[u][0][q];  // two v_lshl_add
+                                        const int i2 = (((ia[u][5][q] << 8) + ia[u][4][q]) << 8) + ia[u][3][q];
+                                        const double v = ((double)ia[u][6][q] * 16777216.0 + (double)i2) * 16777216.0 + (double)i1;
+                                        accM[r2 + u][t][q] = __builtin_fma(v, fsc, accM[r2 + u][t][q]);
+                                    }
+                            }
+                        }
+                    }
+                    __syncthreads();  // the sample masks and digit planes are free (the staging below rewrites the masks)
+                }
+                if (PREFETCH_A) load_pair(qbA, 6);  // the next tile's first digit pair of the Gram table
+            } else {
+                // mask operand of dims DW wave + 16 r + l15: word 2 (dim / 128) + parity, bit (dim % 128) / 2
+                const int mword = 2 * ((DW * wave) >> 7) + (l15 & 1);
+                unsigned long long mwc = Msc[l4 * 4 + mword];
+                double bwc[NTMB], bsc = 0.0;
+    #pragma unroll
+                for (int t = 0; t < NTMB; ++t) bwc[t] = Ws[l4 * WS + 16 * t + l15];
+                if constexpr (SPLIT) bsc = Ws[l4 * WS + 16 * NTP + PADS + (lane & 3)];
+                // One staging piece follows each MFMA.  Measured (tools/ubench_shadow.hip): v_mfma_f64 holds the
+                // SIMD's VALU port for its 64 cycles -- no VALU instruction of this wave overlaps it, only LDS,
+                // SALU and memory instructions do -- so this interleave hides the staging's LDS writes and the
+                // row-load latency, not its ALU work.  The B operands of step s+1 are read from LDS during step s.
+                // B operand of the 4x4x4 blocks: lane = 16 k + 4 block + j -> W[sample 4 s + k][column j of the group];
+                // its A operand (lane = 16 k + 4 block + i -> dim 4 block + i, sample k) is the SAME register as the
+                // 16x16x4 tiles' (row = lane % 16, k = lane / 16): no extra mask expansion.
+                static_for<8>([&](auto s_tag) {
+                    constexpr int s = decltype(s_tag)::value;
+                    unsigned long long mwn = 0ull;
+                    double bwn[NTMB], bsn = 0.0;
+                    constexpr int PER_R = NTMB + (SPLIT ? 1 : 0);  // MFMAs per row tile and k-step
+                    constexpr int SLOTS = RT * PER_R;
+                    static_for<SLOTS>([&](auto i_tag) {
+                        constexpr int i = decltype(i_tag)::value, r = i / PER_R, t = i % PER_R;
+                        // am = bit ? 1.0 : 0.0 in two ops: sign-extended 1-bit field (0 / -1) & high word of 1.0
+                        const int sh = (((DW * wave) & 127) >> 1) + 8 * r;
+                        const int am_hi = __builtin_amdgcn_sbfe((int)(unsigned)(mwc >> (sh & 32)), (sh & 31) + (l15 >> 1), 1) & 0x3FF00000;
+                        const double am = __hiloint2double(am_hi, 0);
+                        if constexpr (t < NTMB) {
+                            accM[r][t] = mfma(am, bwc[t], accM[r][t]);
+                        } else {
+                            accS[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, bsc, accS[r], 0, 0, 0);
+                        }
+                        if constexpr (s < RPW) {  // the row's pieces spread evenly over the step's MFMAs
+                            constexpr int P0 = i * STAGE_PIECES / SLOTS, P1 = (i + 1) * STAGE_PIECES / SLOTS;
+                            static_for<P1 - P0>([&](auto o_tag) {
+                                stage_piece(tile + 1, lane, s_tag, std::integral_constant<int, P0 + decltype(o_tag)::value>{});
+                            });
+                        }
+                        if constexpr (i == SLOTS * 3 / 4 && s + 1 < 8) {
+                            const int smp = 4 * (s + 1) + l4;
+                            mwn = Msc[smp * 4 + mword];
+    #pragma unroll
+                            for (int tt = 0; tt < NTMB; ++tt) bwn[tt] = Ws[smp * WS + 16 * tt + l15];
+                            if constexpr (SPLIT) bsn = Ws[smp * WS + 16 * NTP + PADS + (lane & 3)];
+                        }
+                    });
+                    if constexpr (s + 1 < 8) {
+                        mwc = mwn;
+    #pragma unroll
+                        for (int t = 0; t < NTMB; ++t) bwc[t] = bwn[t];
+                        bsc = bsn;
                     }
                 });
-                if constexpr (s + 1 < 8) {
-                    mwc = mwn;
-#pragma unroll
-                    for (int t = 0; t < NTMB; ++t) bwc[t] = bwn[t];
-                    bsc = bsn;
-                }
-            });
+            }
             stage_end(lane, (int)((tile + 1 - tile_begin) & 1));
 #ifdef PPCA_PHASE_TIMING
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: charge the prefetch wait to P4
@@ -1031,6 +1243,23 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int dim = DW * wave + 16 * r + l4 + 4 * q;  // C/D row of v_mfma_f64_16x16x4
+                if constexpr (P4I8) {
+                    const int dimi = DW * wave + 16 * r + 4 * l4 + q;  // C/D row of v_mfma_i32_16x16x64_i8
+                    if (dimi < d) {
+#pragma unroll
+                        for (int t = 0; t < NCT; ++t) {
+                            const int c = 16 * t + l15, a = c - KP;
+                            if (c < KP) out[L.S + (int64_t)dimi * KP + c] = accM[r][t][q];
+                            else if (a < K) out[L.U + (int64_t)dimi * K + a] = accM[r][t][q];
+                            else if (a == K) out[L.totals + dimi] = accM[r][t][q];
+                        }
+                    }
+                    if (dim < d) {
+                        if (l15 < K) out[L.cross + (int64_t)dim * K + l15] = accX[r][q];
+                        else if (l15 == K) out[L.sumx + dim] = accX[r][q];
+                    }
+                    continue;
+                }
                 if (dim >= d) continue;
 #pragma unroll
                 for (int t = 0; t < NTP; ++t) {
@@ -1052,7 +1281,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     out[L.sumx + dim] = accX[r][q];
                 }
             }
-            if constexpr (SPLIT) {  // 4x4x4 group: D lane = 16 i + 4 block + j
+            if constexpr (SPLIT && !P4I8) {  // 4x4x4 group: D lane = 16 i + 4 block + j
                 const int dim = DW * wave + 16 * r + 4 * ((lane >> 2) & 3) + (lane >> 4);
                 const int a = PADS + (lane & 3);  // index in [w z | w]
                 if (dim < d) {
