@@ -97,7 +97,8 @@ int ppca_ctx_synchronize(ppca_ctx *ctx);
 /* Device blocks released by a context's buffers (output datasets, scratch) are kept
  * for its next allocation of about the same size instead of going through
  * hipFree / hipMalloc (0.2-0.4 s a pair at 8 GB, 30x the kernel that fills them);
- * at most PPCA_POOL_GB GiB (default min(64, a quarter of the device); 0 disables).
+ * at most PPCA_POOL_GB GiB (default min(32, an eighth of the device); 0 disables).
+ * The cache is invisible to other allocators of the process (torch's): trim before large allocations made elsewhere.
  * ppca_ctx_trim returns the kept blocks to the device now; an allocation hipMalloc
  * refuses for lack of memory does the same for every context before retrying. */
 int ppca_ctx_trim(ppca_ctx *ctx, int64_t *released_bytes);

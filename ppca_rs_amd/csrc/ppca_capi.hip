@@ -45,11 +45,12 @@ static size_t pool_round(size_t bytes) {
     const size_t q = bytes >= (size_t(1) << 20) ? (size_t(2) << 20) : 512;
     return (std::max<size_t>(bytes, 8) + q - 1) / q * q;
 }
-void *DevPool::take(size_t cap) {
+void *DevPool::take(size_t cap, size_t *real_cap) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = blocks.lower_bound(cap);
     if (it == blocks.end() || it->first > cap + cap / 4) return nullptr;
     void *p = it->second;
+    *real_cap = it->first;  // the block keeps its own capacity: it goes back to the cache under that size
     cached -= it->first;
     blocks.erase(it);
     return p;
@@ -99,8 +100,10 @@ static std::shared_ptr<DevPool> make_pool(hipStream_t stream) {
     auto pool = std::make_shared<DevPool>();
     pool->stream = stream;
     size_t free_b = 0, total_b = 0;
-    size_t limit = size_t(64) << 30;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = std::min(limit, total_b / 4);
+    // (the cache is invisible to other allocators of the process -- torch's among them: a torch out-of-memory does not
+    //  empty it; call ppca_ctx_trim before large allocations made elsewhere.  Hence the modest default.)
+    size_t limit = size_t(32) << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = std::min(limit, total_b / 8);
     if (const char *e = getenv("PPCA_POOL_GB")) limit = (size_t)(std::max(atof(e), 0.0) * (double)(size_t(1) << 30));
     pool->limit = limit;
     std::lock_guard<std::mutex> lk(g_pools_mu);
@@ -124,7 +127,11 @@ int ppca_host::dev_alloc(size_t bytes, BufRef *out) {
     std::shared_ptr<DevPool> pool = g_pool ? *g_pool : nullptr;
     if (pool && pool->limit == 0) pool = nullptr;
     b->cap = pool ? pool_round(bytes) : std::max<size_t>(bytes, 8);
-    if (pool) b->p = pool->take(b->cap);
+    if (pool) {
+        size_t real = b->cap;
+        b->p = pool->take(b->cap, &real);
+        if (b->p) b->cap = real;
+    }
     if (!b->p) {
         hipError_t e = hipMalloc(&b->p, b->cap);
         if (e == hipErrorOutOfMemory) {  // cached blocks of this or another context may be what is in the way

@@ -238,11 +238,27 @@ extern "C" int ppca_em_step_group(ppca_comm *const *comms, int32_t n, ppca_datas
     for (int i = 0; i < n; ++i)
         if (!comms[i] || !shards[i] || !models_in[i] || !models_out[i]) return fail(PPCA_ERR_INVALID, "null argument");
     const StatsLayout L(models_in[0]->d, models_in[0]->k);
+    // Everything that can be refused is refused HERE, before any lock is taken or anything is enqueued on any device:
+    // a failure half-way through the launch loop would leave the earlier devices with a pass in flight and an
+    // all-reduce their peers never join.
+    for (int i = 0; i < n; ++i) {
+        if (comms[i]->n_ranks != n) return fail(PPCA_ERR_INVALID, "communicator %d belongs to a clique of %d, not %d", i, comms[i]->n_ranks, n);
+        if (models_in[i]->d != L.d || models_in[i]->k != L.k || models_out[i]->d != L.d || models_out[i]->k != L.k)
+            return fail(PPCA_ERR_INVALID, "model shapes differ (rank %d)", i);
+        if (models_out[i] == models_in[i] || models_out[i]->buf == models_in[i]->buf)
+            return fail(PPCA_ERR_INVALID, "out may not alias model_in (rank %d)", i);
+        if (shards[i]->d != L.d) return fail(PPCA_ERR_INVALID, "shard %d has %d dimensions but the model has output size %d", i, shards[i]->d, L.d);
+        const int dev = comms[i]->ctx->device;
+        if (shards[i]->ctx->device != dev || models_in[i]->ctx->device != dev || models_out[i]->ctx->device != dev)
+            return fail(PPCA_ERR_INVALID, "shard / models of rank %d do not live on its communicator's device %d", i, dev);
+        for (int j = 0; j < i; ++j)
+            if (comms[j]->ctx->device == dev) return fail(PPCA_ERR_INVALID, "communicators %d and %d share device %d", j, i, dev);
+    }
+    if (ppca_path_kind(L.d, L.k) < 0) return fail(PPCA_ERR_UNSUPPORTED, "state size %d is not supported", L.k);
     std::vector<std::unique_lock<std::recursive_mutex>> locks;
     for (int i = 0; i < n; ++i) locks.emplace_back(comms[i]->ctx->mu);
     for (int i = 0; i < n; ++i) {
         ppca_ctx *ctx = comms[i]->ctx;
-        if (models_in[i]->d != L.d || models_in[i]->k != L.k) return fail(PPCA_ERR_INVALID, "model shapes differ");
         if (int rc = use_device(ctx)) return rc;
         if (int rc = ensure(ctx->stats, ctx->stats_cap, sizeof(double) * (size_t)L.len)) return rc;
         if (int rc = ppca_em_accumulate(ctx, shards[i], models_in[i], static_cast<double *>(ctx->stats->p))) return rc;

@@ -190,6 +190,24 @@ __device__ __forceinline__ void mfma_i8_x7(const i4_t &a, const i4_t (&b)[7], i4
         : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]));
 }
 
+// Three / one independent v_mfma_i32_16x16x64_i8 with a shared A operand (C = 0), results in VGPRs (see mfma_i8_x7).
+__device__ __forceinline__ void mfma_i8_x3(const i4_t &a, const i4_t &b0, const i4_t &b1, const i4_t &b2, i4_t &d0, i4_t &d1, i4_t &d2) {
+    asm volatile(
+        "v_mfma_i32_16x16x64_i8 %0, %3, %4, 0\n\t"
+        "v_mfma_i32_16x16x64_i8 %1, %3, %5, 0\n\t"
+        "v_mfma_i32_16x16x64_i8 %2, %3, %6, 0\n\t"
+        "s_nop 7"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2)
+        : "v"(a), "v"(b0), "v"(b1), "v"(b2));
+}
+__device__ __forceinline__ void mfma_i8_x1(const i4_t &a, const i4_t &b0, i4_t &d0) {
+    asm volatile(
+        "v_mfma_i32_16x16x64_i8 %0, %1, %2, 0\n\t"
+        "s_nop 7"
+        : "=&v"(d0)
+        : "v"(a), "v"(b0));
+}
+
 template <int K>
 constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
 

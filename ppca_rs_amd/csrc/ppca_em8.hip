@@ -1,0 +1,870 @@
+// ppca_em8.hip -- the EM pass (E-step + every M-step reduction in ONE sweep over X, as pass_kernel) as an
+// EIGHT-wave workgroup, two waves per SIMD, with two roles:
+//
+//   front waves 0-3   P1 staging of a tile's rows, P2 [G | b] (int8-sliced Gram + fp64-MFMA b = X~ C), P3 the
+//                     per-sample k x k solve, P4a the x~-side statistics cross / sumx on the fp64 MFMA
+//   back waves 4-7    P4b: S / U / totals (256 x 66) += Mask^T [wP | wz | w] on the INT8 MFMA with exact 64-bit
+//                     integer accumulation: rows of [wP | wz | w] cut into seven signed bytes of a fixed-point form,
+//                     64 samples (two tiles) per v_mfma_i32_16x16x64_i8, digit sums folded into int64 accumulators
+//
+// Why this split (round 3):  v_mfma_f64 shares the SIMD's vector port with every other vector
+// instruction of every wave (tools/ubench_shadow.hip), and P4b was 8.8 k of a tile's 13.9 k fp64-MFMA cycles.  With
+// one exact operand (the 0/1 mask) P4b does not need the fp64 pipe at all: on the int8 MFMA it is 70 x 16 cycles of
+// the MATRIX pipe per tile plus ~700 integer vector instructions (digit cutting, recombination) -- work that leaves
+// the fp64 port alone and so can run on the second wave of each SIMD in the gaps of the front role's dependent fp64
+// chains (the Cholesky pivots, LDS operand waits).  The round-2 role split failed because its second role WAS fp64
+// MFMAs; the round-2 int8 P4b failed because it ran on the same wave as everything else.  Registers: the back role
+// holds the 160 accumulator registers (int64, so no fp64 conversion on the per-group path) and nothing of the solver;
+// the front role holds the solver and none of the mask-side accumulators: both fit 256.
+//
+// Fixed-point form.  Column c of [wP | wz | w] has ONE exponent E_c per workgroup: I = rint(w 2^(50 - E_c)), |I| < 2^50,
+// cut by one fused multiply-add onto the magic constant 1.5 2^52 + 0x808080808080 (the mantissa then IS the biased
+// integer; xor with the constant's own bits leaves the balanced bytes).  E_c = exponent of the first tile's column
+// maximum + 6.  A later tile whose entry does not fit raises a flag (any exponent field other than 0x433 after the
+// add: too large, infinite or NaN alike); the back waves then contract what is pending under the old exponents,
+// flush the int64 accumulators into the workgroup's partial (x 2^(E_c - 50), fp64), raise the exponents and cut the
+// tile again -- a cold path, taken once at the first tile and whenever a column outgrows its scale.  The integer sums
+// are exact; the only rounding is the cut itself (<= 2^-45 of the column's first-tile maximum per entry) and the one
+// conversion per flush.  A non-finite column poisons its exponent: NaN reaches the statistics as through fp64.
+// Accumulators are also flushed every 100 groups (64 samples x 2^50 per group stay below 2^63).
+//
+// Hand-off (all in LDS): the front writes the tile's [wP | wz | w] rows in P3, ONE workgroup barrier per tile; the back
+// cuts them into digit planes (even tile of a group: its own region; odd tile: the [G | b] buffer, free after P3) and
+// contracts a group when its second tile is there.  The front waits on a counter of finished back iterations before
+// it overwrites [G | b] or the rows (normally long satisfied: the back's ~4 k cycles per tile sit beside ~16 k of
+// front work).  Per-dimension sample masks of the last three tiles are kept (16 bytes per dimension), so the staging
+// of tile t+1 never touches what the contraction of tiles t-1, t reads.
+//
+// Replaces in the reference: infer (ppca/src/ppca_model.rs:221-227), the cross moment (:281-293), the d second-moment
+// scans (:294-306), the noise 4-tuple (:328-358) and llk (:142-149) -- as pass_kernel, whose per-sample arithmetic,
+// tile order and summation orders the front role keeps (cross, sumx, the scalars and the llk are bit-identical to it).
+#include <atomic>
+#include <cstdlib>
+
+#include "ppca_device.hpp"
+
+namespace ppca {
+
+constexpr int E8_QW = 7;        // signed bytes per entry
+constexpr int E8_F = 50;        // |I| < 2^F
+constexpr int E8_HEAD = 6;      // binary orders kept free above the column maximum of the tile that set the scale
+constexpr int E8_POISON = 100000;
+constexpr int E8_EMIN = -900, E8_EMAX = 1000;
+constexpr int E8_FLUSH_GROUPS = 100;
+
+template <int K>
+struct Cfg8 {
+    using c = Cfg<K>;
+    static constexpr int KP = c::KP, NTP = c::NTP, B = c::B, DP = c::DP, XS = c::XS, CS = c::CS;
+    static constexpr int NC = KP + K + 1;        // statistic columns [wP | wz | w]
+    static constexpr int NCT = (NC + 15) / 16;   // 16-column tiles of them
+    static constexpr int NCOL = 16 * NCT;
+    static constexpr int GS = 16 * NTP + 17;     // [G (16 NTP) | b partial of dims 0-127 (16) | pad]
+    static constexpr int BS = K + 1;             // b partial of dims 128-255 (odd or not: K + 1 doubles per sample)
+    static constexpr int WS = 16 * NTP + 18;     // [wP (K') .. | wz (K) | w | 0 ..]
+    static constexpr int PLANE_BYTES = E8_QW * 2 * NCOL * 16;  // digit planes of one tile: [plane][16-sample chunk][column][16 B]
+    static constexpr int OFF_X = 0;
+    static constexpr int OFF_C = OFF_X + B * XS;
+    static constexpr int OFF_G = OFF_C + DP * CS;
+    static constexpr int OFF_B1 = OFF_G + B * GS;
+    static constexpr int OFF_W = OFF_B1 + B * BS;
+    static constexpr int OFF_M = OFF_W + B * WS;          // mask words, two parities x B x 4 u64
+    static constexpr int OFF_MB = OFF_M + 2 * B * 4;      // sample masks per dimension: DP x 4 u32 (slot = tile % 3)
+    static constexpr int OFF_S = OFF_MB + DP * 2;         // cross-wave scratch
+    static constexpr int OFF_L = OFF_S + 2 * B;           // running scalars: sq[4][2 B] | dev | llk | w | ne | pm | px
+    static constexpr int OFF_P0 = OFF_L + 14 * B;         // digit planes of a group's first tile
+    static constexpr int OFF_E = OFF_P0 + PLANE_BYTES / 8;  // column exponents (NCOL ints), flags
+    static constexpr int OFF_BAR = OFF_E + NCOL / 2 + 4;  // counters: front barrier, back barrier, back iterations done, violation stamp
+    static constexpr int LDS_DOUBLES = OFF_BAR + 4;
+    static_assert(PLANE_BYTES <= B * GS * 8, "the odd tile's digit planes fit the [G | b] buffer");
+    static_assert(NCOL / 2 <= 64, "one back wave digitises NCOL / 2 (column, chunk) items");
+    static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget");
+};
+
+// Barrier among the four waves of one role on a monotonic LDS counter.  A wave's LDS operations execute in order, so
+// its add follows its stores; the others read only after seeing the count.
+__device__ __forceinline__ void role_barrier(unsigned *ctr, unsigned &target, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    target += 4;
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+        const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(seen - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wait_counter(const unsigned *ctr, unsigned need) {
+    for (;;) {
+        const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(seen - need) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+#ifdef PPCA_PHASE_TIMING
+#define E8_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define E8_STAMP(i)
+#endif
+
+template <int K, bool GATHER>
+__global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
+    using cfg = Cfg8<K>;
+    constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS, BS = cfg::BS,
+                  WS = cfg::WS, NC = cfg::NC, NCT = cfg::NCT, NCOL = cfg::NCOL;
+    constexpr int NF = 4;              // waves per role
+    constexpr int RPW = B / NF;        // rows staged per front wave
+    constexpr int DPS = cfg::DP / 2;   // dims per K-split of b = X~ C
+    constexpr int STEPS = DPS / 4;
+    constexpr int RT = 16 / NF;        // 16-dim row tiles per wave in P4
+    constexpr int DW = cfg::DP / NF;   // dims owned by a wave in P4
+    constexpr int QW = E8_QW;
+    static_assert(NTP <= NF, "int8 Gram: one front wave per packed-column tile");
+    static_assert(QS == 8, "digit grouping assumes 8 slices");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Xs = sm + cfg::OFF_X;
+    double *Cs = sm + cfg::OFF_C;
+    double *Gs = sm + cfg::OFF_G;
+    double *B1 = sm + cfg::OFF_B1;
+    double *Ws = sm + cfg::OFF_W;
+    unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
+    unsigned *Mb = reinterpret_cast<unsigned *>(sm + cfg::OFF_MB);
+    double *xxs = sm + cfg::OFF_S;
+    double *scl = sm + cfg::OFF_L;
+    int *Ex = reinterpret_cast<int *>(sm + cfg::OFF_E);
+    unsigned *ctr = reinterpret_cast<unsigned *>(sm + cfg::OFF_BAR);
+    unsigned *fbar = ctr, *bbar = ctr + 1, *bdone = ctr + 2, *vstamp = ctr + 3;
+
+    if (p.qflag) {  // qprep's dynamic-range guard: the fp64-Gram pass_kernel runs instead
+        int unsafe = 0;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) unsafe |= p.qflag[t];
+        if (unsafe) return;
+    }
+    const int tid = threadIdx.x, lane_entry = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool front = wave8 < NF;
+    const int wave = wave8 & (NF - 1);  // index within the role
+    const int d = p.d;
+    const int64_t n = p.n_dev ? (int64_t)*p.n_dev : p.n;
+    const double *mC = p.model + MODEL_HDR;
+    const double *mMean = mC + (int64_t)d * K;
+    const double s2 = p.model[1], lnsig = p.model[2];
+
+    for (int idx = tid; idx < cfg::DP * CS; idx += 512) {
+        int j = idx / CS, a = idx - j * CS;
+        Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
+    }
+    for (int idx = tid; idx < B * WS; idx += 512) Ws[idx] = 0.0;
+    constexpr bool PAIRS = K >= 2;
+    constexpr int SQW = PAIRS ? 2 * B : B;  // sq slots per front wave
+    constexpr int L_DEV = NF * SQW, L_LLK = L_DEV + B, L_W = L_DEV + 2 * B, L_NE = L_DEV + 3 * B, L_PM = L_DEV + 4 * B,
+                  L_PX = L_DEV + 5 * B;
+    static_assert(L_DEV + 6 * B <= 14 * B, "scalar slots");
+    for (int idx = tid; idx < L_DEV + 6 * B; idx += 512) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
+    for (int idx = tid; idx < cfg::DP * 4; idx += 512) Mb[idx] = 0u;
+    if (tid < 4) ctr[tid] = 0u;
+
+    const int64_t ntiles = (n + B - 1) / B;
+    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+#ifdef PPCA_PHASE_TIMING
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#endif
+    __syncthreads();
+
+#ifdef E8_ONLY_FRONT
+    if (!front) return;
+#endif
+#ifdef E8_ONLY_BACK
+    if (front) return;
+#endif
+    if (!front) {
+        // =========================================================== back role: P4b on the int8 MFMA
+        long long accM[RT][NCT][4];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int t = 0; t < NCT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) accM[r][t][q] = 0ll;
+        unsigned bbar_target = 0u;
+        unsigned attempt = 0u;   // digitise attempts so far (the violation stamp of the current one)
+        int pending = 0;         // 1: the previous tile's planes wait in P0 for their partner
+        int have_scale = 0, flushed = 0, groups = 0;
+        unsigned char *smb = reinterpret_cast<unsigned char *>(sm);
+        constexpr int P0_BYTES = cfg::OFF_P0 * 8, PG_BYTES = cfg::OFF_G * 8;
+        StatsLayout L(d, K);
+        double *out = p.part + (int64_t)blockIdx.x * L.len;
+
+        // [wP | wz | w] column c of W row -> its slot
+        auto wsrc = [&](int c) { return c < KP ? c : 16 * NTP + (c - KP); };
+
+        // ---- digit planes of the current tile's rows under the exponents Ex; returns (wave-uniform) whether an entry
+        // of a live column did not fit.  Item = (column c, 16-sample chunk): NCOL / 2 items per wave.
+        auto digitise = [&](int lane, int dst_bytes) -> bool {
+            asm volatile("" : "+v"(lane));  // (addresses recomputed here, not hoisted and parked across the other phases)
+            const bool active = lane < NCOL / 2;
+            const int it = (NCOL / 2) * wave + (active ? lane : 0);
+            const int c = it >> 1, chunk = it & 1;
+            const bool cvalid = c < NC;
+            const int src = cvalid ? wsrc(c) : 0;
+            const int E = Ex[c];
+            const bool poisoned = E > 5000;
+            const double qsc = __hiloint2double((1023 + E8_F - (poisoned ? 0 : E)) << 20, 0);
+            const double magic = __hiloint2double(0x43388080, (int)0x80808080);
+            unsigned bad = 0u;
+            unsigned pl[QW][4];
+            const double *wsrcp = Ws + (16 * chunk) * WS + src;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // four samples at a time (the live set stays small next to the 160 accumulator registers)
+                unsigned wlo[4], whi[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // mantissa of w 2^(F - E) + magic = 2^51 + 0x808080808080 + I: xor with the constant's own bits leaves
+                    // bytes 0..5 = the balanced digits and bits 48..51 = the top digit (4-bit two's complement)
+                    const double wv = wsrcp[(4 * g4 + j) * WS];
+                    const double v = __builtin_fma(cvalid ? wv : 0.0, qsc, magic);
+                    const unsigned lo = (unsigned)__double2loint(v) ^ 0x80808080u;
+                    const unsigned hi = (unsigned)__double2hiint(v) ^ 0x43388080u;
+                    bad |= hi;  // any exponent field other than 0x433: the entry does not fit (or is not finite)
+                    const int top = __builtin_amdgcn_sbfe((int)hi, 16, 4);
+                    wlo[j] = lo;
+                    whi[j] = __builtin_amdgcn_perm((unsigned)top, hi, 0x0C040100u);  // [d4, d5, d6, 0]
+                }
+                // 4 x 4 byte transposes: plane k of samples 4 g .. 4 g + 3 = bytes k of their four words
+                auto tr4 = [&](const unsigned *w, unsigned *o0, unsigned *o1, unsigned *o2, unsigned *o3) {
+                    const unsigned t0 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), t1 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
+                    const unsigned u0 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), u1 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
+                    *o0 = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+                    *o1 = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+                    *o2 = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+                    if (o3) *o3 = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+                };
+                tr4(wlo, &pl[0][g4], &pl[1][g4], &pl[2][g4], &pl[3][g4]);
+                tr4(whi, &pl[4][g4], &pl[5][g4], &pl[6][g4], nullptr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (active) {
+                unsigned char *wq = smb + dst_bytes;
+#pragma unroll
+                for (int sl = 0; sl < QW; ++sl)
+                    *reinterpret_cast<i4_t *>(wq + ((sl * 2 + chunk) * NCOL + c) * 16) =
+                        i4_t{(int)pl[sl][0], (int)pl[sl][1], (int)pl[sl][2], (int)pl[sl][3]};
+            }
+            const bool mine = active && cvalid && !poisoned && (bad >> 20) != 0u;
+            return __builtin_amdgcn_ballot_w64(mine) != 0ull;
+        };
+
+        // ---- new exponents from the current tile's column maxima (cold path)
+        auto rescale = [&](int lane) {
+            asm volatile("" : "+v"(lane));
+            const bool active = lane < NCOL / 2;
+            const int it = (NCOL / 2) * wave + (active ? lane : 0);
+            const int c = it >> 1, chunk = it & 1;
+            const bool cvalid = c < NC;
+            const int src = cvalid ? wsrc(c) : 0;
+            double m = 0.0;
+            bool fin = true;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double av = __builtin_fabs(cvalid ? Ws[(16 * chunk + j) * WS + src] : 0.0);
+                fin = fin && (av < __builtin_inf());
+                m = __builtin_fmax(m, av);
+            }
+            m = __builtin_fmax(m, dpp_f64<0xB1, 0xF>(m));  // the other chunk of the column sits in the neighbouring lane
+            const int finw = __builtin_amdgcn_update_dpp(0, fin ? 1 : 0, 0xB1, 0xF, 0xF, true);
+            fin = fin && finw != 0;
+            const int Eold = have_scale ? Ex[c] : E8_EMIN;
+            int Enew = Eold;
+            if (m > 0.0) {
+                int e = __builtin_amdgcn_frexp_exp(m) + E8_HEAD;  // |w| < 2^(e - HEAD)
+                e = e < E8_EMIN ? E8_EMIN : e;
+                Enew = e > Eold ? e : Eold;
+            }
+            if (!fin || Enew > E8_EMAX) Enew = E8_POISON;
+            if (Eold > 5000) Enew = Eold;  // (a poisoned column stays poisoned)
+            if (active && chunk == 0) Ex[c] = Enew;
+        };
+
+        // ---- accumulators -> the workgroup's partial (x 2^(E - F)); C/D row of v_mfma_i32_16x16x64_i8 = 4 (lane / 16) + reg
+        auto emit = [&](int lane, bool accumulate, bool clear) {
+            asm volatile("" : "+v"(lane));
+            const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const int c = 16 * t + l15, a = c - KP;
+                const int E = have_scale ? Ex[c] : 0;
+                const double fsc = __hiloint2double(E > 5000 ? 0x7FF80000 : (1023 + E - E8_F) << 20, 0);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int dim = DW * wave + 16 * r + 4 * l4 + q;
+                        double v = have_scale ? (double)accM[r][t][q] * fsc : 0.0;
+                        if (E > 5000) v = fsc;  // poisoned column: NaN whatever the integers hold
+                        if (clear) accM[r][t][q] = 0ll;
+                        if (dim < d && c < NC) {
+                            double *dst = c < KP ? out + L.S + (int64_t)dim * KP + c
+                                                 : (a < K ? out + L.U + (int64_t)dim * K + a : out + L.totals + dim);
+                            *dst = accumulate ? *dst + v : v;
+                        }
+                    }
+            }
+        };
+
+        // ---- one contraction: the group in [P0 | G-region planes] (both == false: P0 alone), sample masks of slots
+        // slot_first / slot_second; digit sums folded into the int64 accumulators
+        auto contract = [&](int lane, bool both, int slot_first, int slot_second) {
+            asm volatile("" : "+v"(lane));
+            const int l15 = lane & 15, l4 = lane >> 4, lh = l4 >> 1;
+            i4_t af[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const unsigned word = Mb[(DW * wave + 16 * r + l15) * 4 + (lh ? slot_second : slot_first)];
+                unsigned f = (word >> (16 * (l4 & 1))) & 0xFFFFu;
+                f = (both || lh == 0) ? f : 0u;
+                // rows were shifted in first-to-last: row r of a byte at bit 7 - r; after the bit reversal samples 0..7
+                // of the chunk sit at bits 24..31, samples 8..15 at bits 16..23, ascending
+                const unsigned g = __builtin_bitreverse32(f);
+                af[r][0] = (int)((((g >> 24) & 0xFu) * 0x00204081u) & 0x01010101u);
+                af[r][1] = (int)((((g >> 28) & 0xFu) * 0x00204081u) & 0x01010101u);
+                af[r][2] = (int)((((g >> 16) & 0xFu) * 0x00204081u) & 0x01010101u);
+                af[r][3] = (int)((((g >> 20) & 0xFu) * 0x00204081u) & 0x01010101u);
+            }
+            const unsigned char *wq = smb + (lh == 0 ? P0_BYTES : PG_BYTES) + ((l4 & 1) * NCOL + l15) * 16;
+            constexpr int PSTRIDE = 2 * NCOL * 16;  // bytes between digit planes
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                // planes in three batches {0,1,2}, {3,4,5}, {6}: 24-bit pieces of the sums, each added to the int64
+                // accumulators on its own (twelve operand and twelve result registers in flight, not 28 + 28)
+                const unsigned char *wt = wq + t * 256;
+                {
+                    const i4_t b0 = *reinterpret_cast<const i4_t *>(wt), b1 = *reinterpret_cast<const i4_t *>(wt + PSTRIDE),
+                               b2 = *reinterpret_cast<const i4_t *>(wt + 2 * PSTRIDE);
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        i4_t d0, d1, d2;
+                        mfma_i8_x3(af[r], b0, b1, b2, d0, d1, d2);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)  // D row = 4 l4 + q (dim 16 r + 4 l4 + q), column l15
+                            accM[r][t][q] += (long long)((((d2[q] << 8) + d1[q]) << 8) + d0[q]);  // |.| < 2^30
+                    }
+                }
+                {
+                    const i4_t b3 = *reinterpret_cast<const i4_t *>(wt + 3 * PSTRIDE), b4 = *reinterpret_cast<const i4_t *>(wt + 4 * PSTRIDE),
+                               b5 = *reinterpret_cast<const i4_t *>(wt + 5 * PSTRIDE);
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        i4_t d3, d4, d5;
+                        mfma_i8_x3(af[r], b3, b4, b5, d3, d4, d5);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            accM[r][t][q] += (long long)((((d5[q] << 8) + d4[q]) << 8) + d3[q]) << 24;
+                    }
+                }
+                {
+                    const i4_t b6 = *reinterpret_cast<const i4_t *>(wt + 6 * PSTRIDE);
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        i4_t d6;
+                        mfma_i8_x1(af[r], b6, d6);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) accM[r][t][q] += (long long)d6[q] << 48;
+                    }
+                }
+            }
+        };
+
+        for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
+            int lane = lane_entry;
+            asm volatile("" : "+v"(lane));
+            const int rel = (int)(tile - tile_begin);
+            const bool last = tile + 1 == tile_end;
+            const int slot_cur = rel % 3, slot_prev = (rel + 2) % 3;
+            __syncthreads();  // front: P3(tile) done -> the tile's W rows are final
+            E8_STAMP(4)
+#pragma unroll 1
+            for (;;) {  // normally one trip
+                ++attempt;
+                const bool bad = !have_scale || digitise(lane, pending ? PG_BYTES : P0_BYTES);
+                if (bad && lane == 0) __hip_atomic_store(vstamp, attempt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                role_barrier(bbar, bbar_target, lane_entry);
+                E8_STAMP(5)
+                const bool viol = __builtin_amdgcn_readfirstlane(__hip_atomic_load(vstamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == attempt;
+                // What is contracted now: a fitting tile completes its group (or is the last tile: alone); a tile that does
+                // not fit sends what is pending in alone, under the old exponents -- then (cold path) the integers leave
+                // for the partial, the exponents rise and the tile is cut again.
+                const bool con = pending || (!viol && last);
+                if (con) {
+                    contract(lane, !viol && pending, pending ? slot_prev : slot_cur, slot_cur);
+                    ++groups;
+                }
+                pending = (!viol && !con) ? 1 : 0;
+                if (viol ? have_scale != 0 : groups >= E8_FLUSH_GROUPS) {
+                    emit(lane, flushed != 0, true);
+                    flushed = 1;
+                    groups = 0;
+                }
+                if (!viol) break;
+                role_barrier(bbar, bbar_target, lane_entry);  // every wave has read the old exponents
+                rescale(lane);
+                have_scale = 1;
+                role_barrier(bbar, bbar_target, lane_entry);
+            }
+            E8_STAMP(6)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane_entry == 0) __hip_atomic_fetch_add(bdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        emit(lane_entry, flushed != 0, false);
+#ifdef PPCA_PHASE_TIMING
+        if (p.dbg && tid == 256)
+            for (int i = 4; i < 8; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
+#endif
+        return;
+    }
+
+    // =============================================================== front role
+    unsigned fbar_target = 0u;
+    double mu[4];  // staging lane map: lane l holds dims 128 h + 2 l + e (element q = 2 h + e) of a row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int j = 128 * (q >> 1) + 2 * lane_entry + (q & 1);
+        mu[q] = (j < d) ? mMean[j] : 0.0;
+    }
+    d4_t accX[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) accX[r] = d4_t{0, 0, 0, 0};
+    const double inv_s2 = 1.0 / s2;
+    double xr[RPW][4];
+    // observed <=> |x| < lim: +inf for a real dimension (finite test, dataset.rs:19-22), -1 for the padding past d
+    double lim[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lim[q] = (128 * (q >> 1) + 2 * lane_entry + (q & 1) < d) ? __builtin_inf() : -1.0;
+    const int64_t nleft = n - tile_begin * B;
+    const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));  // rows from the workgroup's first row to the end
+    const double *Xwg = p.X + tile_begin * B * p.ldx;
+    const int64_t own = (tile_end - tile_begin) * B;
+    const int nmine = tile_end > tile_begin ? (int)(own < nleft ? own : nleft) : 0;
+    const int *rows_wg = (GATHER && p.rows) ? p.rows + tile_begin * B : nullptr;
+    const int rowbytes = d * (int)sizeof(double);
+    // one buffer descriptor per tile (base = its first row, extent = its real rows): the row is a scalar offset, the
+    // lane offset one constant VGPR, the half an immediate; rows past n read as zeros
+    auto tile_rsrc = [&](int64_t tile) {
+        const int rel0 = (int)(tile - tile_begin) * B;
+        int cnt = nrel - rel0;
+        cnt = __builtin_amdgcn_readfirstlane(cnt < 0 ? 0 : (cnt > B ? B : cnt));
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Xwg + (int64_t)rel0 * p.ldx), 0, cnt * rowbytes, 0x00020000);
+    };
+    auto load_row = [&](const __amdgpu_buffer_rsrc_t &trs, int64_t tile, int r) {
+        typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+        if constexpr (GATHER) {
+            if (rows_wg) {
+                const int rel = (int)(tile - tile_begin) * B + wave * RPW + r;
+                const int rc = rel < nrel ? rel : nrel - 1;
+                const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<double *>(p.X + (int64_t)rows_wg[rc < 0 ? 0 : rc] * p.ldx), 0, rc < 0 ? 0 : rowbytes, 0x00020000);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, 0);
+                    xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+                    xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(trs, lane_entry * 16, (wave * RPW + r) * rowbytes + 1024 * h, 0);
+            xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+            xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
+    const bool gram_wave = NTP >= NF || wave < NTP;
+    i4_t qbA[2][4];
+    auto load_pair = [&](i4_t(&dst)[2][4], int sl0) {
+        int qbase = wave * QS * 4 * 1024;
+        asm volatile("" : "+s"(qbase));
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16 + kc * 1024, qbase + (sl0 + u) * 4096, 0);
+                dst[u][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+            }
+    };
+    // ---- P1: one tile = RPW rows per front wave.  The finite-test ballots ARE the mask words (word 2 h + e of a row,
+    // bit l <-> dim 128 h + 2 l + e; qprep orders the digit table to match); each lane also shifts its own bit of every
+    // ballot into st_mb (v_addc with the ballot as carry-in): after the wave's eight rows, byte = this dimension over
+    // those samples (row r at bit 7 - r) -- the A operand of the back role's contraction.
+    int st_wlo = 0, st_whi = 0;
+    int st_mb[4] = {0, 0, 0, 0};
+    double xx_run = 0.0;  // sum_i w_i |x~_i|^2 of this wave's rows (sigma^2 and the llk are linear in it)
+    auto stage_row = [&](int64_t t, int lane, auto r_tag) {
+        constexpr int r = decltype(r_tag)::value;
+        const int ri = wave * RPW + r;
+        double pc_xx = 0.0;
+        static_for<2>([&](auto h_tag) {
+            constexpr int h = decltype(h_tag)::value;
+            double xt[2];
+            unsigned long long bal[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double v = xr[r][2 * h + e];
+                const bool ob = __builtin_fabs(v) < lim[2 * h + e];
+                bal[e] = __builtin_amdgcn_ballot_w64(ob);
+                xt[e] = ob ? v - mu[2 * h + e] : 0.0;  // select, never multiply (utils.rs:118-127)
+            }
+            file_mask<4 * r + 2 * h>(st_wlo, st_whi, st_mb[2 * h], bal[0]);
+            file_mask<4 * r + 2 * h + 1>(st_wlo, st_whi, st_mb[2 * h + 1], bal[1]);
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 * h + 2 * lane) = d2_t{xt[0], xt[1]};
+            pc_xx += xt[0] * xt[0];
+            pc_xx += xt[1] * xt[1];
+        });
+        // wave-uniform: a real row of one of THIS workgroup's tiles
+        const bool mine = (int)(t - tile_begin) * B + ri < nmine;
+        const double wr = mine ? (p.w ? p.w[t * B + ri] : 1.0) : 0.0;  // (scalar load)
+        xx_run += wr * pc_xx;
+    };
+    auto stage_tile = [&](int64_t t, int lane) {
+        const int rel = (int)(t - tile_begin);
+        st_wlo = st_whi = 0;
+        st_mb[0] = st_mb[1] = st_mb[2] = st_mb[3] = 0;
+        static_for<RPW>([&](auto r_tag) { stage_row(t, lane, r_tag); });
+        const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
+        if (lane < 4 * RPW) Ms[(rel & 1) * 4 * B + wave * 4 * RPW + lane] = myw;
+        unsigned char *mbb = reinterpret_cast<unsigned char *>(Mb);
+        const int slot = rel % 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            mbb[(128 * (q >> 1) + 2 * lane + (q & 1)) * 16 + 4 * slot + wave] = (unsigned char)st_mb[q];
+    };
+
+    if (tile_begin < tile_end) {
+        const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile_begin);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) load_row(trs, tile_begin, r);
+        load_pair(qbA, 6);
+        stage_tile(tile_begin, lane_entry);
+    }
+    role_barrier(fbar, fbar_target, lane_entry);
+
+    for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
+        int lane = lane_entry;
+        asm volatile("" : "+v"(lane));
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int colb = (l15 < K) ? l15 : K;
+        const int rel = (int)(tile - tile_begin);
+        const unsigned long long *Msc = Ms + (rel & 1) * 4 * B;
+        // ------------------------------------------------------------ P2: [G | b] of the tile
+        {
+            const int rt = wave & 1, kq = wave >> 1;
+            const int si = 16 * rt + l15;
+            d4_t accb = d4_t{0, 0, 0, 0};
+            const double *xrow = Xs + si * XS + DPS * kq + l4;
+            const double *cpc = Cs + (DPS * kq + l4) * CS + colb;
+            i4_t af[2][4];
+            double v[2][4];
+            // one digit pair: contract, then fold the exact integer digit sums (|sum| <= 2^14) into the running fp64
+            // value, Horner in 128^2
+            auto group = [&](const i4_t(*qb)[4], bool first) {
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2) {
+                    i4_t ia[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        ia[u] = i4_t{0, 0, 0, 0};
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc)
+                            ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[rt2][kc], qb[u][kc], ia[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int part = ia[1][r] * 128 + ia[0][r];
+                        v[rt2][r] = first ? (double)part : v[rt2][r] * 16384.0 + (double)part;
+                    }
+                }
+            };
+            double qs = 0.0;
+            i4_t qbB[2][4];
+            {
+                unsigned long long mwd[2][4];
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) mwd[rt2][kc] = Msc[(16 * rt2 + l15) * 4 + kc];
+                __builtin_amdgcn_sched_barrier(0);
+                load_pair(qbB, 4);
+                if (gram_wave) qs = p.qscale[16 * wave + l15];
+                __builtin_amdgcn_sched_barrier(0);
+                // A = mask bytes: lane (sample 16 rt2 + l15, k-chunk kc, 16 l4 .. +15 of it); 4 bits -> 4 bytes by one
+                // multiply: (x * 0x204081) & 0x01010101 puts bit i of x into byte i
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) {
+                        const unsigned bits = (unsigned)(mwd[rt2][kc] >> (16 * l4)) & 0xFFFFu;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            af[rt2][kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
+                    }
+                group(qbA, true);   // digits {7,6}: requested during the previous tile's P4a
+                load_pair(qbA, 2);
+                group(qbB, false);  // digits {5,4}
+                load_pair(qbB, 0);
+            }
+            {
+                // b = X~ C: operands of the next four k-steps are requested before the current four MFMAs issue
+                constexpr int CH = 4;
+                double axb[2][CH], cbb[2][CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    axb[0][u] = xrow[4 * u];
+                    cbb[0][u] = cpc[4 * u * CS];
+                }
+#pragma unroll
+                for (int c = 0; c < STEPS / CH; ++c) {
+                    if (c + 1 < STEPS / CH) {
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
+                            cbb[(c + 1) & 1][u] = cpc[4 * ((c + 1) * CH + u) * CS];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) accb = mfma(axb[c & 1][u], cbb[c & 1][u], accb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            group(qbA, false);  // digits {3,2}
+            group(qbB, false);  // digits {1,0}
+            E8_STAMP(0)
+            // [G | b] may still hold the previous tile's digit planes: wait until the back role has finished that tile
+            wait_counter(bdone, 4u * (unsigned)rel);
+            if (gram_wave) {
+#pragma unroll
+                for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)  // C/D map of the 16x16 integer MFMA: row = 4 (lane >> 4) + reg
+                        Gs[(16 * rt2 + 4 * l4 + r) * GS + 16 * wave + l15] = v[rt2][r] * qs;
+            }
+            // the two K-split partials of b are summed by the solver in a fixed order (p0 + p1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kq == 0) Gs[(16 * rt + l4 + 4 * r) * GS + 16 * NTP + l15] = accb[r];
+                else if (l15 < K + 1) B1[(16 * rt + l4 + 4 * r) * BS + l15] = accb[r];
+            }
+        }
+        role_barrier(fbar, fbar_target, lane_entry);
+        E8_STAMP(1)
+        // ------------------------------------------------------------ P3: per-sample k x k solve
+        // Every front wave factors every sample (lane = sample, lanes 32-63 mirror 0-31) and the waves share the
+        // independent columns of M^-1, two per instruction stream (lane i: column 2p, lane i + 32: column 2p + 1);
+        // wave 0 also owns z, llk and the scalars.  (The rows of W are free: the back role has cut the previous
+        // tile's -- the counter above.)
+        if (PAIRS || lane < B) {
+            const int i = lane & (B - 1);
+            const int hi = PAIRS ? lane >> 5 : 0;
+            const int64_t row = tile * B + i;
+            const double *g0 = Gs + i * GS;
+            const double *b1 = B1 + i * BS;
+            const double wgt = (row < n) ? (p.w ? p.w[row] : 1.0) : 0.0;
+            const int m = __popcll(Msc[i * 4]) + __popcll(Msc[i * 4 + 1]) + __popcll(Msc[i * 4 + 2]) + __popcll(Msc[i * 4 + 3]);
+            double *wrow = Ws + i * WS;
+            double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;
+            const double sq_run = scl[wave * SQW + (PAIRS ? lane : i)];
+            Posterior<K> post;
+            double pm;
+            int pe;
+            post.factor([&](int e) { return g0[e]; }, s2, pm, pe);
+            double z[K], quad, zz;
+            post.solve([&](int a) { return g0[16 * NTP + a] + b1[a]; }, z, quad, zz);
+            double trpart = 0.0;
+            if constexpr (PAIRS) {
+#pragma unroll
+                for (int pp = 0; pp < (K + 1) / 2; ++pp) {
+                    if (pair_owner(K, pp, NF) != wave) continue;
+                    const int c0 = 2 * pp;
+                    const double zc = (hi && c0 + 1 < K) ? z[c0 + 1 < K ? c0 + 1 : c0] : z[c0];
+                    // P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439), weighted
+                    trpart += post.minv_column_pair(c0, hi, [&](int t, double v, bool ok) {
+                        if (ok && c0 + hi < K) wrow[tri(t, c0) + hi] = wgt * (z[t] * zc + s2 * v);
+                    });
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    if (column_owner(K, c, NF) != wave) continue;
+                    trpart += post.minv_column(c, [&](int a, int cc, double v) { wrow[tri(a, cc)] = wgt * (z[a] * z[cc] + s2 * v); });
+                }
+            }
+            // tr(C_o Sigma C_o^T) = <Sigma, G> = s2 (K - s2 tr M^-1)  (:345); all-masked samples are filtered out (:333)
+            if (m > 0) sc_sq -= wgt * s2 * s2 * trpart;
+            if (wave == 0 && hi == 0) {
+                const double run_dev = scl[L_DEV + i], run_llk = scl[L_LLK + i], run_w = scl[L_W + i], run_ne = scl[L_NE + i];
+                const double run_pm = scl[L_PM + i], run_px = scl[L_PX + i];
+                double *zrow = wrow + 16 * NTP;  // W row = [w P (K') | 0.. | w z (K) | w | 0..]
+#pragma unroll
+                for (int a = 0; a < K; ++a) zrow[a] = wgt * z[a];
+                zrow[K] = wgt;
+                if (m > 0) {
+                    sc_sq += wgt * s2 * (double)K;
+                    sc_dev += wgt * (0.0 - quad - s2 * zz);  // |x~ - C_o z|^2 minus |x~|^2, added in the epilogue (:346)
+                    sc_ne += (row < n) ? 1.0 : 0.0;
+                }
+                const double lk0 = sample_llk_nolog(0.0, quad, inv_s2, lnsig, m, K);
+                if (p.w) {
+                    if (!p.no_llk) sc_llk += wgt * (m > 0 ? lk0 - 0.5 * Posterior<K>::logdet(pm, pe) : 0.0);
+                } else {
+                    const bool use = m > 0 && row < n;  // wgt is 1 for real rows
+                    sc_llk += use ? lk0 : 0.0;
+                    int e;
+                    scl[L_PM + i] = frexp(run_pm * (use ? pm : 1.0), &e);
+                    scl[L_PX + i] = run_px + (double)(e + (use ? pe : 0));
+                }
+                sc_w += wgt;
+                scl[L_DEV + i] = run_dev + sc_dev;
+                scl[L_LLK + i] = run_llk + sc_llk;
+                scl[L_W + i] = run_w + sc_w;
+                scl[L_NE + i] = run_ne + sc_ne;
+            }
+            scl[wave * SQW + (PAIRS ? lane : i)] = sq_run + sc_sq;
+        }
+        E8_STAMP(2)
+        __syncthreads();  // the tile's W rows are final: the back role starts on them
+        // ------------------------------------------------------------ P4a: cross / sumx += X~^T [wz | w]
+        // the only reader of the x~ tile; the next tile's rows are requested one per k-step behind the MFMAs
+        {
+            load_pair(qbA, 6);  // the next tile's first digit pair (the table does not depend on the tile)
+            double bzb[2], axb[2][RT];
+            const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile + 1);
+            bzb[0] = Ws[l4 * WS + 16 * NTP + l15];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) axb[0][r] = Xs[l4 * XS + DW * wave + 16 * r + l15];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s < RPW) load_row(trs, tile + 1, s);  // unconditional (rows past the end read as zeros)
+                if (s + 1 < 8) {
+                    const int smp = 4 * (s + 1) + l4;
+                    bzb[(s + 1) & 1] = Ws[smp * WS + 16 * NTP + l15];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) axb[(s + 1) & 1][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s & 1][r], bzb[s & 1], accX[r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        role_barrier(fbar, fbar_target, lane_entry);  // the x~ tile is free
+        E8_STAMP(3)
+        // ------------------------------------------------------------ P1 of the next tile
+        stage_tile(tile + 1, lane);
+        role_barrier(fbar, fbar_target, lane_entry);
+        E8_STAMP(0)
+    }
+#ifdef PPCA_PHASE_TIMING
+    if (p.dbg && tid == 0)
+        for (int i = 0; i < 4; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
+#endif
+
+    // ---------------------------------------------------------------- epilogue (front waves)
+    {
+        const int lane = lane_entry, l15 = lane & 15, l4 = lane >> 4;
+        const double sq_w = wave_sum(lane < SQW ? scl[wave * SQW + lane] : 0.0);
+        const double xx_w = wave_sum(xx_run);
+        if (lane == 0) {
+            xxs[wave] = sq_w;
+            xxs[NF + wave] = xx_w;
+        }
+        role_barrier(fbar, fbar_target, lane_entry);
+        StatsLayout L(d, K);
+        double *out = p.part + (int64_t)blockIdx.x * L.len;
+        if (wave == 0) {
+            double v0 = 0.0, xx_tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NF; ++w) v0 += xxs[w];
+#pragma unroll
+            for (int w = 0; w < NF; ++w) xx_tot += xxs[NF + w];
+            const int li = lane < B ? lane : 0;
+            double sc_llk = scl[L_LLK + li];
+            sc_llk -= 0.5 * (log(scl[L_PM + li]) + scl[L_PX + li] * LN_2);
+            const double v1 = wave_sum(lane < B ? scl[L_DEV + li] : 0.0), v2 = wave_sum(lane < B ? sc_llk : 0.0),
+                         v3 = wave_sum(lane < B ? scl[L_W + li] : 0.0), v4 = wave_sum(lane < B ? scl[L_NE + li] : 0.0);
+            if (lane == 0) {
+                double *sc = out + L.scalars;
+                sc[SC_SQERR] = v0;
+                sc[SC_DEVSQ] = v1 + xx_tot;
+                sc[SC_LLK] = v2 - 0.5 * inv_s2 * xx_tot;
+                sc[SC_SUMW] = v3;
+                sc[SC_NONEMPTY] = v4;
+                sc[5] = 0.0;
+                sc[6] = 0.0;
+                sc[7] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int dim = DW * wave + 16 * r + l4 + 4 * q;  // C/D row of v_mfma_f64_16x16x4
+                if (dim >= d) continue;
+                if (l15 < K) out[L.cross + (int64_t)dim * K + l15] = accX[r][q];
+                else if (l15 == K) out[L.sumx + dim] = accX[r][q];
+            }
+    }
+}
+
+// ------------------------------------------------------------------ launcher
+template <int K, bool GATHER>
+static hipError_t launch_em8_t(int grid, const PassArgs &a, hipStream_t s) {
+    const size_t lds = sizeof(double) * Cfg8<K>::LDS_DOUBLES;
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&em8_kernel<K, GATHER>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((em8_kernel<K, GATHER>), dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+bool em8_covers(int k) {
+#ifdef PPCA_DEV_K10
+    return k == 10;
+#else
+    return k >= 1 && k <= FUSED_MAX_K;
+#endif
+}
+
+hipError_t launch_em8(int k, int grid, const PassArgs &a, hipStream_t s) {
+    const bool gather = a.rows != nullptr;
+#define PPCA_E8_CASE(KK) \
+    case KK:             \
+        return gather ? launch_em8_t<KK, true>(grid, a, s) : launch_em8_t<KK, false>(grid, a, s);
+    switch (k) {
+#ifdef PPCA_DEV_K10
+        PPCA_E8_CASE(10)
+#else
+        PPCA_E8_CASE(1) PPCA_E8_CASE(2) PPCA_E8_CASE(3) PPCA_E8_CASE(4) PPCA_E8_CASE(5) PPCA_E8_CASE(6) PPCA_E8_CASE(7)
+        PPCA_E8_CASE(8) PPCA_E8_CASE(9) PPCA_E8_CASE(10)
+#endif
+        default: return hipErrorInvalidValue;
+    }
+#undef PPCA_E8_CASE
+}
+
+}  // namespace ppca

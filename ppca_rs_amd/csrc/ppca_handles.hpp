@@ -18,7 +18,7 @@
 // context's buffers are kept and handed to its next allocation of about the same size.  Reuse is ordered by the
 // context's one stream; give() waits for that stream first, which is the guarantee hipFree gave (work still queued
 // against the block finishes before anybody else can own it).  Bounded by `limit` bytes (PPCA_POOL_GB, default
-// min(64 GiB, a quarter of the device)); emptied by ppca_ctx_trim, by ppca_ctx_destroy, and by any allocation of the
+// min(32 GiB, an eighth of the device)); emptied by ppca_ctx_trim, by ppca_ctx_destroy, and by any allocation of the
 // process that hipMalloc refuses for lack of memory.
 struct DevPool {
     std::mutex mu;
@@ -26,7 +26,7 @@ struct DevPool {
     bool alive = true;
     size_t cached = 0, limit = 0;
     std::multimap<size_t, void *> blocks;  // capacity -> block
-    void *take(size_t cap);
+    void *take(size_t cap, size_t *real_cap);
     void give(void *p, size_t cap);
     size_t trim();
     void shutdown();

@@ -26,6 +26,8 @@ struct PassArgs {
     const double *w;      // n weights or nullptr (= 1)
     const int *rows;      // EM mode, nullable: gathered pass -- sample i is physical row rows[i] of X (w is indexed by i)
     int64_t n;
+    const int *n_dev;     // nullable: the number of samples is read from device memory instead of n (gathered passes whose
+                          // row count was produced on the device: no host round trip); the grid is sized for an upper bound
     int d;
     const double *model;  // device model buffer
     // EM mode
@@ -58,6 +60,10 @@ int fused_gram_tiles(int k);  // number of qflag entries the guard writes for st
 // Launchers.  Return hipSuccess or the launch error.
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s);
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);
+// The EM pass as an eight-wave workgroup, two roles (ppca_em8.hip): front waves stage / [G | b] / solve / cross, back
+// waves contract the mask-side statistics on the int8 MFMA.  Honours a.qflag like the int8 instantiation of pass_kernel.
+bool em8_covers(int k);
+hipError_t launch_em8(int k, int grid, const PassArgs &a, hipStream_t s);
 // The log-likelihood sweep alone (ppca_llk.hip): per-sample llks (nullable) and the per-workgroup scalars; honours
 // a.qflag like the int8 instantiation of pass_kernel.
 hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s);

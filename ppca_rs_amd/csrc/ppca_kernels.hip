@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bases stay in SGPRs
     const int l15 = lane & 15, l4 = lane >> 4;
     const int d = p.d;
-    const int64_t n = p.n;
+    const int64_t n = p.n_dev ? (int64_t)*p.n_dev : p.n;
     const double *mC = p.model + MODEL_HDR;
     const double *mMean = mC + (int64_t)d * K;
     const double s2 = p.model[1], lnsig = p.model[2];
@@ -1625,6 +1625,15 @@ static int gram_mode() {
     return v;
 }
 
+// PPCA_EM8=0: the four-wave pass_kernel for the EM pass (A/B runs against the eight-wave role-split kernel)
+static bool em8_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_EM8");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+
 static bool llk2_enabled() {
     static const bool v = [] {
         const char *e = getenv("PPCA_LLK2");
@@ -1652,6 +1661,7 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
             if (!b.states && !b.covs && !b.recon && llk2_enabled()) return launch_llk2(K, grid, b, s);
         }
         if constexpr (EM) {
+            if (em8_enabled() && em8_covers(K)) return launch_em8(K, grid, b, s);  // eight waves, two roles (ppca_em8.hip)
             if (b.rows) return launch_pass_t<K, EM, 4, true, true>(grid, b, s);
         }
         return launch_pass_t<K, EM, 4, true>(grid, b, s);

@@ -8,15 +8,16 @@ C = os.path.join(ROOT, "ppca_rs_amd", "csrc")
 flags = ["-DPPCA_DEV_K10"] + [a for a in sys.argv[1:] if a.startswith("-D")] + (["-DPPCA_PHASE_TIMING"] if "--timing" in sys.argv else [])
 base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags]
 procs = [subprocess.Popen(base + ["-c", os.path.join(C, "ppca_kernels.hip"), "-o", "/tmp/ppca_kernels.dev.o"]),
+         subprocess.Popen(base + ["-c", os.path.join(C, "ppca_em8.hip"), "-o", "/tmp/ppca_em8.dev.o"]),
          subprocess.Popen(base + ["-c", os.path.join(C, "ppca_llk.hip"), "-o", "/tmp/ppca_llk.dev.o"])]
 if "--timing" in sys.argv:  # ppca_capi prints the phase table only when built with the flag
     procs.append(subprocess.Popen(base + ["-c", os.path.join(C, "ppca_capi.hip"), "-o", "/tmp/ppca_capi.dev.o"]))
 if "--asm" in sys.argv:
-    for src, out in (("ppca_kernels.hip", "/tmp/k10.s"), ("ppca_llk.hip", "/tmp/llk10.s")):
+    for src, out in (("ppca_kernels.hip", "/tmp/k10.s"), ("ppca_em8.hip", "/tmp/em8.s"), ("ppca_llk.hip", "/tmp/llk10.s")):
         procs.append(subprocess.Popen(base + ["--offload-device-only", "-S", os.path.join(C, src), "-o", out], stderr=subprocess.DEVNULL))
 assert all(p.wait() == 0 for p in procs)
 capi = "/tmp/ppca_capi.dev.o" if "--timing" in sys.argv else os.path.join(C, "ppca_capi.o")
 out = os.path.join(ROOT, "ppca_rs_amd", "libppca_hip_dev.so")
-subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out, "/tmp/ppca_kernels.dev.o", "/tmp/ppca_llk.dev.o",
+subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out, "/tmp/ppca_kernels.dev.o", "/tmp/ppca_em8.dev.o", "/tmp/ppca_llk.dev.o",
                                   os.path.join(C, "ppca_generic.o"), os.path.join(C, "ppca_comm.o"), capi])
 print(out)
