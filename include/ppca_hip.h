@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPCA_ABI_VERSION 2
+#define PPCA_ABI_VERSION 3
 
 typedef enum ppca_status {
     PPCA_OK = 0,
@@ -241,6 +241,18 @@ int ppca_em_step_sharded(ppca_comm *comm, ppca_dataset *shard, const ppca_model 
 int ppca_em_step_group(ppca_comm *const *comms, int32_t n, ppca_dataset *const *shards, ppca_model *const *models_in,
                        const ppca_prior *prior, ppca_model *const *models_out, double *llk_in);
 
+/* PPCAMix::iterate_with_prior (mix.rs:281-337) over ALL row shards in ONE call per rank (BASELINE configuration 5):
+ * this rank's responsibilities (K log-likelihood sweeps), an all-reduce(MAX) of the K per-component maxima of
+ * ln w_i + log r_ic (:312-317 take them over all samples), the K weighted component passes (rows of negligible weight
+ * dropped, see ppca_mix_component_stats), ONE all-reduce(SUM) of [K statistic buffers | K weight sums | llk], and the
+ * identical finalisation and new log-weights (:324-325, :335) on every rank -- everything enqueued on the context
+ * stream, the shifts computed on the device, one synchronisation at the end for the (K + 1) returned values.
+ * models_in / models_out: n_models handles on the communicator's device (state sizes may differ per component);
+ * llk_in (nullable): mixture log-likelihood of the input over all shards.  A rank whose shard is empty still calls. */
+int ppca_mix_em_step_sharded(ppca_comm *comm, ppca_dataset *shard, ppca_model *const *models_in,
+                             const double *log_weights_in, int32_t n_models, const ppca_prior *prior,
+                             ppca_model *const *models_out, double *log_weights_out, double *llk_in);
+
 /* ---------------------------------------------------------------- mixture */
 /* PPCAMix::iterate_with_prior mix.rs:281-337 on one GPU: per-sample
  * responsibilities (log-softmax of llk_c + log pi_c, :283-295), per-component
@@ -265,8 +277,9 @@ int ppca_mix_responsibilities_dev(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *c
                                   int32_t n_models, double *u_dev, double *lse_dev);
 /* One component of the sharded M-step in one call: weights exp(u_i - shift) (mix.rs:320-323; shift = the maximum over
  * ALL shards), their sum over this shard (nullable), and the component's weighted statistics (ppca_stats_len doubles,
- * device).  Rows whose weight is exactly zero add exactly nothing to any statistic and are skipped: the pass gathers
- * the others (rows_used, nullable, reports how many).  Synchronises. */
+ * device).  Every statistic is linear in the weights, so rows whose weight is below 2^-200 of the component's largest
+ * (their terms sit >= 147 binary orders below the fp64 resolution of the sums they would join) are dropped: the pass
+ * gathers the others (rows_used, nullable, reports how many).  Synchronises. */
 int ppca_mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, const double *u_dev, double shift,
                              double *stats_dev, double *sum_host, int64_t *rows_used);
 int ppca_vector_max_dev(ppca_ctx *ctx, const double *v_dev, int64_t n, double *max_host);

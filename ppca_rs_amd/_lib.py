@@ -116,6 +116,7 @@ SIGNATURES = {
     "ppca_comm_backend": (C.c_char_p, []),
     "ppca_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "ppca_em_step_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), C.c_void_p, c_double_p]),
+    "ppca_mix_em_step_sharded": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, C.POINTER(Prior), c_void_pp, C.c_void_p, c_double_p]),
     "ppca_em_step_group": (C.c_int, [c_void_pp, C.c_int32, c_void_pp, c_void_pp, C.POINTER(Prior), c_void_pp, c_double_p]),
     "ppca_gram_engine": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p]),
     "ppca_debug_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

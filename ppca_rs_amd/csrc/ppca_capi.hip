@@ -167,6 +167,18 @@ int ppca_host::use_device(const ppca_ctx *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     return PPCA_OK;
 }
+int ppca_host::ensure_hstage(ppca_ctx *ctx, size_t bytes) {
+    if (ctx->hstage && ctx->hstage_cap >= bytes) return PPCA_OK;
+    if (ctx->hstage) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        (void)hipHostFree(ctx->hstage);
+        ctx->hstage = nullptr;
+    }
+    const size_t cap = std::max<size_t>(bytes, 8192);
+    HIP_TRY(hipHostMalloc(&ctx->hstage, cap, hipHostMallocDefault));
+    ctx->hstage_cap = cap;
+    return PPCA_OK;
+}
 
 // ------------------------------------------------------------------ misc
 extern "C" const char *ppca_last_error(void) { return g_err.c_str(); }
@@ -230,6 +242,9 @@ extern "C" int ppca_ctx_destroy(ppca_ctx *ctx) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
+    if (ctx->hstage) (void)hipHostFree(ctx->hstage);
+    for (void *q : ctx->pin)
+        if (q) (void)hipHostFree(q);
     if (ctx->pool) ctx->pool->shutdown();  // buffers that outlive the context (datasets, models) fall back to hipFree
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -589,7 +604,7 @@ static int check_pair(const ppca_dataset *ds, const ppca_model *model) {
 // rows / wsel / nsel: gathered pass over nsel rows of the dataset (fused path only): sample i is row rows[i] with
 // weight wsel[i]; rows == nullptr: the whole dataset with its own weights.
 static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_dev, const int *rows,
-                              const double *wsel, int64_t nsel) {
+                              const double *wsel, int64_t nsel, const int *nsel_dev = nullptr) {
     if (!ctx || !stats_dev) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
     USE_CTX(ctx);
@@ -624,6 +639,7 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
     a.w = rows ? wsel : ds->w;
     a.rows = rows;
     a.n = n;
+    a.n_dev = rows ? nsel_dev : nullptr;  // gathered pass whose row count lives on the device (nsel = upper bound)
     a.d = ds->d;
     a.model = model->p();
     a.part = static_cast<double *>(ctx->part->p);
@@ -663,6 +679,10 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
                 t[10] / tiles, t[11] / tiles, t[2] / tiles, (t[3] + t[4] + t[5] + t[6] + t[7] + t[15]) / tiles,
                 (t[4] + t[6]) / tiles, t[7] / tiles, t[3] / tiles, tiles);
         fprintf(stderr, "[ppca P4b int8 cycles/tile] staging %.0f  digitise %.0f  contraction + barriers + stores %.0f\n", t[5] / tiles, t[15] / tiles, t[7] / tiles);
+        // (the eight-wave kernel writes slots 8..15; the four-wave kernel's slots 0..7 are then its idle instantiation's)
+        fprintf(stderr, "[em8 cycles/tile] front: P2 compute %.0f  wait back + stores + barrier %.0f  P3 %.0f  wg barrier + P4a + barrier %.0f  staging + barrier %.0f"
+                        " | back: wait at wg barrier %.0f  digitise + barrier %.0f  contraction / flush %.0f\n",
+                t[8] / tiles, t[9] / tiles, t[10] / tiles, t[11] / tiles, t[12] / tiles, t[13] / tiles, t[14] / tiles, t[15] / tiles);
     }
 #endif
     return PPCA_OK;
@@ -1025,16 +1045,17 @@ static int mix_posteriors(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *mo
     }
     for (int c = 0; c < nm; ++c)
         if (int rc = ppca_llks_dev(ctx, ds, models[c], static_cast<double *>(llk->p) + (size_t)c * n)) return rc;
-    // normalised log-weights (PPCAMix::new mix.rs:66-70)
-    std::vector<double> lw(log_weights, log_weights + nm);
-    double mx = lw[0];
-    for (double v : lw) mx = std::max(mx, v);
+    // normalised log-weights (PPCAMix::new mix.rs:66-70), through the context's pinned staging buffer: an asynchronous
+    // copy (every entry point that uses the staging ends with a synchronisation, so it is free at the next call)
+    if (int rc = ensure_hstage(ctx, sizeof(double) * 256)) return rc;
+    double *lw = static_cast<double *>(ctx->hstage);
+    double mx = log_weights[0];
+    for (int c = 0; c < nm; ++c) mx = std::max(mx, log_weights[c]);
     double s = 0.0;
-    for (double v : lw) s += std::exp(v - mx);
-    for (double &v : lw) v = v - mx - std::log(s);
+    for (int c = 0; c < nm; ++c) s += std::exp(log_weights[c] - mx);
+    for (int c = 0; c < nm; ++c) lw[c] = log_weights[c] - mx - std::log(s);
     double *work = static_cast<double *>(ctx->work->p);
-    HIP_TRY(hipMemcpyAsync(work + 1536, lw.data(), sizeof(double) * nm, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyAsync(work + 1536, lw, sizeof(double) * nm, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(launch_mix_posteriors(static_cast<double *>(llk->p), work + 1536, ds->w, n, nm, static_cast<double *>(u->p),
                                   static_cast<double *>(lse->p), logpost ? static_cast<double *>((*logpost)->p) : nullptr,
                                   ctx->stream));
@@ -1069,21 +1090,22 @@ extern "C" int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *
     return PPCA_OK;
 }
 
-// One component of the mixture M-step on this context's rows: sample weights exp(u_i - shift) (mix.rs:320-323), their
-// sum (:324-325), and the component's weighted statistics.  Rows whose weight is exactly zero contribute exactly
-// nothing to any statistic (all are linear in the weights): on the fused path they are dropped from the pass
-// (select_* kernels), which then gathers the remaining rows -- at d = 256 the exponential underflows for most samples
-// of the other clusters, so the K component passes together cost about as much as one.
-static int mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, const double *u_dev,
-                               const double *shift_dev, double *stats_dev, double *sum_host, int64_t *rows_used) {
-    USE_CTX(ctx);
+// One component of the mixture M-step on this context's rows, ENQUEUED only (no host synchronisation): sample weights
+// exp(u_i - *shift_dev) (mix.rs:320-323), their sum (:324-325) into *sum_dev, and the component's weighted statistics
+// into stats_dev.  Every statistic is linear in the weights, so rows whose weight is below 2^-200 of the component's
+// largest (SEL_MIN_WEIGHT, ppca_kernels.hip: their terms sit >= 147 binary orders below the fp64 resolution of the sums
+// they would join) are dropped from the pass on the fused path: select_* kernels build the ascending row list and its
+// length ON THE DEVICE, the pass gathers those rows and reads the count from device memory (PassArgs::n_dev) -- at
+// d = 256 a sample keeps weight in about one component, so the K component passes together cost about as much as one.
+static int mix_component_enqueue(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, const double *u_dev,
+                                 const double *shift_dev, double *stats_dev, double *sum_dev, const int **rows_used_dev) {
     const int64_t n = ds->n;
     double *work = static_cast<double *>(ctx->work->p);
     const StatsLayout L(model->d, model->k);
+    if (rows_used_dev) *rows_used_dev = nullptr;
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * (size_t)L.len, ctx->stream));
-        if (sum_host) *sum_host = 0.0;
-        if (rows_used) *rows_used = 0;
+        HIP_TRY(hipMemsetAsync(sum_dev, 0, sizeof(double), ctx->stream));
         return PPCA_OK;
     }
     if (int rc = ensure(ctx->mix[4], ctx->mix_cap[4], sizeof(double) * (size_t)n)) return rc;
@@ -1094,37 +1116,23 @@ static int mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model
         explicit SkipLlk(ppca_ctx *ctx_) : c(ctx_) { c->skip_llk = 1; }
         ~SkipLlk() { c->skip_llk = 0; }
     } skip(ctx);
-    int rc = PPCA_OK;
     if (fused) {
         const int nb = select_blocks(n);
         if (int e = ensure(ctx->mix[5], ctx->mix_cap[5], sizeof(int) * (size_t)n)) return e;
         if (int e = ensure(ctx->mix[6], ctx->mix_cap[6], sizeof(int) * ((size_t)nb + 1))) return e;
-        BufRef rows = ctx->mix[5], counts = ctx->mix[6];
-        HIP_TRY(launch_select_positive(u_dev, shift_dev, n, static_cast<int *>(counts->p), static_cast<int *>(rows->p), w,
-                                       ctx->stream));
-        int m = 0;
-        HIP_TRY(hipMemcpyAsync(&m, static_cast<int *>(counts->p) + nb, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (rows_used) *rows_used = m;
-        HIP_TRY(launch_reduce_sum(w, nullptr, m, work + 1026, work, ctx->stream));
-        rc = em_accumulate_impl(ctx, ds, model, stats_dev, static_cast<int *>(rows->p), w, m);
-        if (rc == PPCA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PPCA_ERR_HIP, "synchronize failed");
-    } else {
-        HIP_TRY(launch_exp_shift(u_dev, shift_dev, n, w, ctx->stream));
-        HIP_TRY(launch_reduce_sum(w, nullptr, n, work + 1026, work, ctx->stream));
-        if (rows_used) *rows_used = n;
-        ppca_dataset *wds = nullptr;
-        rc = ppca_dataset_with_weights(ds, nullptr, w, &wds);
-        if (rc == PPCA_OK) rc = ppca_em_accumulate(ctx, wds, model, stats_dev);
-        if (rc == PPCA_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PPCA_ERR_HIP, "synchronize failed");
-        ppca_dataset_free(wds);
+        int *rows = static_cast<int *>(ctx->mix[5]->p), *counts = static_cast<int *>(ctx->mix[6]->p);
+        HIP_TRY(launch_select_positive(u_dev, shift_dev, n, counts, rows, w, ctx->stream));
+        HIP_TRY(launch_reduce_sum(w, nullptr, n, sum_dev, work, ctx->stream, counts + nb));
+        if (rows_used_dev) *rows_used_dev = counts + nb;
+        return em_accumulate_impl(ctx, ds, model, stats_dev, rows, w, n, counts + nb);
     }
-    if (rc) return rc;
-    if (sum_host) {
-        HIP_TRY(hipMemcpyAsync(sum_host, work + 1026, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    return PPCA_OK;
+    HIP_TRY(launch_exp_shift(u_dev, shift_dev, n, w, ctx->stream));
+    HIP_TRY(launch_reduce_sum(w, nullptr, n, sum_dev, work, ctx->stream));
+    ppca_dataset *wds = nullptr;
+    int rc = ppca_dataset_with_weights(ds, nullptr, w, &wds);  // (borrows w: freeing the handle frees nothing)
+    if (rc == PPCA_OK) rc = ppca_em_accumulate(ctx, wds, model, stats_dev);
+    ppca_dataset_free(wds);
+    return rc;
 }
 
 extern "C" int ppca_mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, const double *u_dev,
@@ -1132,10 +1140,85 @@ extern "C" int ppca_mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const p
     if (!ctx || !u_dev || !stats_dev) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
     USE_CTX(ctx);
+    if (int rc = ensure_hstage(ctx, 64)) return rc;
     double *work = static_cast<double *>(ctx->work->p);
-    HIP_TRY(hipMemcpyAsync(work + 1025, &shift, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    double *hs = static_cast<double *>(ctx->hstage);
+    hs[0] = shift;
+    HIP_TRY(hipMemcpyAsync(work + 1025, hs, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const int *used_dev = nullptr;
+    if (int rc = mix_component_enqueue(ctx, ds, model, u_dev, work + 1025, stats_dev, work + 1026, &used_dev)) return rc;
+    HIP_TRY(hipMemcpyAsync(hs + 1, work + 1026, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    int *hu = reinterpret_cast<int *>(hs + 2);
+    *hu = (int)ds->n;
+    if (used_dev) HIP_TRY(hipMemcpyAsync(hu, used_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return mix_component_stats(ctx, ds, model, u_dev, work + 1025, stats_dev, sum_host, rows_used);
+    if (sum_host) *sum_host = hs[1];
+    if (rows_used) *rows_used = *hu;
+    return PPCA_OK;
+}
+
+// PPCAMix::iterate_with_prior (mix.rs:281-337) over this context's rows -- all of them (comm == nullptr) or one row
+// shard of several (comm: the library's RCCL communicator) -- enqueued on the context stream without any host
+// synchronisation until the new log-weights and the log-likelihood are read back at the end:
+//   K log-likelihood sweeps -> responsibilities u_ic = ln w_i + log r_ic (:283-309) and the per-sample mixture llk
+//   K maxima of u_c (:312-317)                      [all-reduce(MAX) of K doubles: the maxima are over ALL samples]
+//   shifts on the device (non-finite -> 0); per component: weights exp(u - shift), their sum, row selection, the
+//   gathered weighted EM pass (:320-328)            [ONE all-reduce(SUM) of [K statistics | K sums | llk]]
+//   K finalisations (identical on every rank); new log-weights log_softmax(ln sum_c + shift_c) (:324-325, :335)
+int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppca_model *const *models_in,
+                           const double *log_weights_in, int32_t nm, const ppca_prior *prior, ppca_model *const *models_out,
+                           double *log_weights_out, double *llk_in) {
+    USE_CTX(ctx);
+    const int64_t n = ds->n;
+    for (int c = 0; c < nm; ++c) {
+        if (!models_out[c]) return fail(PPCA_ERR_INVALID, "null output model");
+        if (models_out[c]->d != models_in[c]->d || models_out[c]->k != models_in[c]->k)
+            return fail(PPCA_ERR_INVALID, "model shapes differ (component %d)", c);
+        if (models_out[c] == models_in[c] || models_out[c]->buf == models_in[c]->buf)
+            return fail(PPCA_ERR_INVALID, "out may not alias model_in (component %d)", c);
+    }
+    if (int rc = check_prior(prior)) return rc;
+    // packed buffer: [statistics of component 0 | ... | nm weight sums | llk]; components may differ in state size
+    std::vector<int64_t> off(nm + 1, 0);
+    for (int c = 0; c < nm; ++c) off[c + 1] = off[c] + StatsLayout(models_in[c]->d, models_in[c]->k).len;
+    const int64_t sums_at = off[nm], llk_at = sums_at + nm, total = llk_at + 1;
+    if (int rc = ensure(ctx->mixpack, ctx->mixpack_cap, sizeof(double) * (size_t)total)) return rc;
+    if (int rc = ensure(ctx->mixaux, ctx->mixaux_cap, sizeof(double) * 1024)) return rc;
+    if (int rc = ensure_hstage(ctx, sizeof(double) * 1024)) return rc;
+    double *pack = static_cast<double *>(ctx->mixpack->p);
+    double *aux = static_cast<double *>(ctx->mixaux->p);  // [0, 256): maxima -> shifts; [256, 513): new log-weights, llk
+    double *work = static_cast<double *>(ctx->work->p);
+    BufRef llk, u, lse;
+    if (n > 0) {
+        if (int rc = mix_posteriors(ctx, ds, models_in, log_weights_in, nm, llk, u, lse, nullptr)) return rc;
+        HIP_TRY(launch_reduce_sum(static_cast<double *>(lse->p), ds->w, n, pack + llk_at, work, ctx->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(pack + llk_at, 0, sizeof(double), ctx->stream));
+    }
+    const double *ud = n > 0 ? static_cast<const double *>(u->p) : nullptr;
+    for (int c = 0; c < nm; ++c) HIP_TRY(launch_reduce_max(ud ? ud + (size_t)c * n : nullptr, n, aux + c, work, ctx->stream));
+    if (comm) {
+        if (int rc = ppca_comm_allreduce(comm, aux, nm, 1)) return rc;
+    }
+    HIP_TRY(launch_mix_shift(aux, nm, ctx->stream));
+    ctx->stats_llk_at = -1;
+    for (int c = 0; c < nm; ++c) {
+        if (int rc = mix_component_enqueue(ctx, ds, models_in[c], ud ? ud + (size_t)c * n : nullptr, aux + c, pack + off[c],
+                                           pack + sums_at + c, nullptr))
+            return rc;
+    }
+    if (comm) {
+        if (int rc = ppca_comm_allreduce(comm, pack, total, 0)) return rc;
+    }
+    for (int c = 0; c < nm; ++c)
+        if (int rc = ppca_em_finalize(ctx, models_in[c], pack + off[c], prior, models_out[c])) return rc;
+    HIP_TRY(launch_mix_logweights(pack + sums_at, aux, pack + llk_at, nm, aux + 256, ctx->stream));
+    double *hs = static_cast<double *>(ctx->hstage);
+    HIP_TRY(hipMemcpyAsync(hs, aux + 256, sizeof(double) * (size_t)(nm + 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < nm; ++c) log_weights_out[c] = hs[c];
+    if (llk_in) *llk_in = hs[nm];
+    return PPCA_OK;
 }
 
 extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models_in,
@@ -1145,40 +1228,18 @@ extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *con
     if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models_in, n_models)) return rc;
     if (ds->n == 0) return fail(PPCA_ERR_EMPTY, "dataset is empty");
-    USE_CTX(ctx);
-    const int64_t n = ds->n;
-    const int nm = n_models;
-    BufRef llk, u, lse;
-    if (int rc = mix_posteriors(ctx, ds, models_in, log_weights_in, nm, llk, u, lse, nullptr)) return rc;
-    double *work = static_cast<double *>(ctx->work->p);
-    if (llk_in) {
-        HIP_TRY(launch_reduce_sum(static_cast<double *>(lse->p), ds->w, n, work + 1024, work, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(llk_in, work + 1024, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    std::vector<double> logsum(nm);
-    for (int c = 0; c < nm; ++c) {
-        const double *uc = static_cast<double *>(u->p) + (size_t)c * n;
-        const StatsLayout L(models_in[c]->d, models_in[c]->k);
-        if (int rc = ensure(ctx->stats, ctx->stats_cap, sizeof(double) * (size_t)L.len)) return rc;
-        double *stats = static_cast<double *>(ctx->stats->p);
-        ctx->stats_llk_at = -1;
-        // max (mix.rs:312-317), un-normalised posteriors as weights (:320-323), log-sum (:324-325), weighted step (:326-328)
-        HIP_TRY(launch_reduce_max(uc, n, work + 1025, work, ctx->stream));
-        double mx = 0.0, sum = 0.0;
-        HIP_TRY(hipMemcpyAsync(&mx, work + 1025, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (int rc = mix_component_stats(ctx, ds, models_in[c], uc, work + 1025, stats, &sum, nullptr)) return rc;
-        logsum[c] = std::log(sum) + mx;
-        if (int rc = ppca_em_finalize(ctx, models_in[c], stats, prior, models_out[c])) return rc;
-        if (int rc = ppca_ctx_synchronize(ctx)) return rc;
-    }
-    // :335 robust_log_softmax
-    double mx = logsum[0];
-    for (double v : logsum) mx = std::max(mx, v);
-    double s = 0.0;
-    for (double v : logsum) s += std::exp(v - mx);
-    for (int c = 0; c < nm; ++c) log_weights_out[c] = logsum[c] - mx - std::log(s);
-    return PPCA_OK;
+    return mix_em_step(ctx, nullptr, ds, models_in, log_weights_in, n_models, prior, models_out, log_weights_out, llk_in);
+}
+
+extern "C" int ppca_mix_em_step_sharded(ppca_comm *comm, ppca_dataset *shard, ppca_model *const *models_in,
+                                        const double *log_weights_in, int32_t n_models, const ppca_prior *prior,
+                                        ppca_model *const *models_out, double *log_weights_out, double *llk_in) {
+    if (!comm || !log_weights_in || !models_out || !log_weights_out) return fail(PPCA_ERR_INVALID, "null argument");
+    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
+    if (int rc = mix_check(shard, models_in, n_models)) return rc;  // (an empty shard still takes part in the collectives)
+    ppca_ctx *ctx = ppca_comm_context(comm);
+    if (shard->ctx->device != ctx->device) return fail(PPCA_ERR_INVALID, "the shard does not live on the communicator's device");
+    return mix_em_step(ctx, comm, shard, models_in, log_weights_in, n_models, prior, models_out, log_weights_out, llk_in);
 }
 
 // ---- building blocks of the SHARDED mixture step (one process per GPU; ppca_rs_amd/distributed.py::ShardedMixEM)
@@ -1288,7 +1349,20 @@ extern "C" int ppca_gram_engine(ppca_ctx *ctx, const ppca_model *model, int32_t 
     if (int rc = check_path(model->d, model->k)) return rc;
     USE_CTX(ctx);
     if (ppca_path_kind(model->d, model->k) == 0) {
-        *engine = 1;  // the generic pipeline contracts on the fp64 MFMA
+        // the generic pipeline: int8-sliced contractions behind the same per-model guard, fp64 MFMA when it trips (or
+        // under PPCA_GENERIC_FP64=1)
+        if (int rc = ensure(ctx->gws, ctx->gws_cap, generic_workspace_bytes(model->d, model->k, 1))) return rc;
+        const int *flag_dev = nullptr;
+        int forced = -1;
+        HIP_TRY(generic_gram_guard(model->d, model->k, model->p(), ctx->gws->p, ctx->stream, &flag_dev, &forced));
+        if (forced >= 0) {
+            *engine = forced;
+            return PPCA_OK;
+        }
+        int flag = 0;
+        HIP_TRY(hipMemcpyAsync(&flag, flag_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        *engine = flag ? 1 : 0;
         return PPCA_OK;
     }
     if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;

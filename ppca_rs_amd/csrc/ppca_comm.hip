@@ -180,6 +180,8 @@ extern "C" int ppca_comm_destroy(ppca_comm *comm) {
     return PPCA_OK;
 }
 
+ppca_ctx *ppca_comm_context(ppca_comm *comm) { return comm ? comm->ctx : nullptr; }
+
 extern "C" int32_t ppca_comm_n_ranks(const ppca_comm *comm) { return comm ? comm->n_ranks : 0; }
 extern "C" int32_t ppca_comm_rank(const ppca_comm *comm) { return comm ? comm->rank : -1; }
 

@@ -51,6 +51,12 @@ constexpr int E8_HEAD = 6;      // binary orders kept free above the column maxi
 constexpr int E8_POISON = 100000;
 constexpr int E8_EMIN = -900, E8_EMAX = 1000;
 constexpr int E8_FLUSH_GROUPS = 100;
+#ifndef E8_BACK_PRIO
+#define E8_BACK_PRIO 0
+#endif
+#ifndef E8_FRONT_PRIO
+#define E8_FRONT_PRIO 0
+#endif
 
 template <int K>
 struct Cfg8 {
@@ -59,24 +65,28 @@ struct Cfg8 {
     static constexpr int NC = KP + K + 1;        // statistic columns [wP | wz | w]
     static constexpr int NCT = (NC + 15) / 16;   // 16-column tiles of them
     static constexpr int NCOL = 16 * NCT;
-    static constexpr int GS = 16 * NTP + 17;     // [G (16 NTP) | b partial of dims 0-127 (16) | pad]
-    static constexpr int BS = K + 1;             // b partial of dims 128-255 (odd or not: K + 1 doubles per sample)
-    static constexpr int WS = 16 * NTP + 18;     // [wP (K') .. | wz (K) | w | 0 ..]
+    // [G | b] and the [wP | wz | w] rows share ONE buffer (row stride GS): a sample's Gram and b partial are dead once the
+    // four front waves hold them in registers (a front barrier inside P3), its W row is written after that.
+    //   as [G | b]:  G (16 NTP, K' used) | b partial of dims 0-127 (16) | pad
+    //   as W row:    wP (K') ..          | wz (K) | w | 0 ..
+    static constexpr int GS = 16 * NTP + 18;
+    static constexpr int WS = GS;
+    static constexpr int BS = K + 1;             // b partial of dims 128-255
     static constexpr int PLANE_BYTES = E8_QW * 2 * NCOL * 16;  // digit planes of one tile: [plane][16-sample chunk][column][16 B]
     static constexpr int OFF_X = 0;
     static constexpr int OFF_C = OFF_X + B * XS;
     static constexpr int OFF_G = OFF_C + DP * CS;
+    static constexpr int OFF_W = OFF_G;
     static constexpr int OFF_B1 = OFF_G + B * GS;
-    static constexpr int OFF_W = OFF_B1 + B * BS;
-    static constexpr int OFF_M = OFF_W + B * WS;          // mask words, two parities x B x 4 u64
+    static constexpr int OFF_M = OFF_B1 + B * BS;         // mask words, two parities x B x 4 u64
     static constexpr int OFF_MB = OFF_M + 2 * B * 4;      // sample masks per dimension: DP x 4 u32 (slot = tile % 3)
     static constexpr int OFF_S = OFF_MB + DP * 2;         // cross-wave scratch
     static constexpr int OFF_L = OFF_S + 2 * B;           // running scalars: sq[4][2 B] | dev | llk | w | ne | pm | px
     static constexpr int OFF_P0 = OFF_L + 14 * B;         // digit planes of a group's first tile
-    static constexpr int OFF_E = OFF_P0 + PLANE_BYTES / 8;  // column exponents (NCOL ints), flags
-    static constexpr int OFF_BAR = OFF_E + NCOL / 2 + 4;  // counters: front barrier, back barrier, back iterations done, violation stamp
-    static constexpr int LDS_DOUBLES = OFF_BAR + 4;
-    static_assert(PLANE_BYTES <= B * GS * 8, "the odd tile's digit planes fit the [G | b] buffer");
+    static constexpr int OFF_P1 = OFF_P0 + PLANE_BYTES / 8;  // ... and of its second
+    static constexpr int OFF_E = OFF_P1 + PLANE_BYTES / 8;  // column exponents (NCOL ints), flags
+    static constexpr int OFF_BAR = OFF_E + NCOL / 2 + 4;  // counters: front barrier, back barrier, tiles digitised, violation stamp
+    static constexpr int LDS_DOUBLES = OFF_BAR + 4;  // (8 counters)
     static_assert(NCOL / 2 <= 64, "one back wave digitises NCOL / 2 (column, chunk) items");
     static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget");
 };
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     double *scl = sm + cfg::OFF_L;
     int *Ex = reinterpret_cast<int *>(sm + cfg::OFF_E);
     unsigned *ctr = reinterpret_cast<unsigned *>(sm + cfg::OFF_BAR);
-    unsigned *fbar = ctr, *bbar = ctr + 1, *bdone = ctr + 2, *vstamp = ctr + 3;
+    unsigned *fbar = ctr, *bbar = ctr + 1, *digdone = ctr + 2, *vstamp = ctr + 3;
 
     if (p.qflag) {  // qprep's dynamic-range guard: the fp64-Gram pass_kernel runs instead
         int unsafe = 0;
@@ -157,7 +167,6 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
         int j = idx / CS, a = idx - j * CS;
         Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
     }
-    for (int idx = tid; idx < B * WS; idx += 512) Ws[idx] = 0.0;
     constexpr bool PAIRS = K >= 2;
     constexpr int SQW = PAIRS ? 2 * B : B;  // sq slots per front wave
     constexpr int L_DEV = NF * SQW, L_LLK = L_DEV + B, L_W = L_DEV + 2 * B, L_NE = L_DEV + 3 * B, L_PM = L_DEV + 4 * B,
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     static_assert(L_DEV + 6 * B <= 14 * B, "scalar slots");
     for (int idx = tid; idx < L_DEV + 6 * B; idx += 512) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
     for (int idx = tid; idx < cfg::DP * 4; idx += 512) Mb[idx] = 0u;
-    if (tid < 4) ctr[tid] = 0u;
+    if (tid < 8) ctr[tid] = 0u;
 
     const int64_t ntiles = (n + B - 1) / B;
     const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -192,12 +201,15 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             for (int t = 0; t < NCT; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) accM[r][t][q] = 0ll;
+        // (measured: the back role at a higher priority than the front costs 5 % -- it is off the front's critical path
+        //  and only has to fill the gaps)
+        if (E8_BACK_PRIO) __builtin_amdgcn_s_setprio(E8_BACK_PRIO);
         unsigned bbar_target = 0u;
         unsigned attempt = 0u;   // digitise attempts so far (the violation stamp of the current one)
         int pending = 0;         // 1: the previous tile's planes wait in P0 for their partner
         int have_scale = 0, flushed = 0, groups = 0;
         unsigned char *smb = reinterpret_cast<unsigned char *>(sm);
-        constexpr int P0_BYTES = cfg::OFF_P0 * 8, PG_BYTES = cfg::OFF_G * 8;
+        constexpr int P0_BYTES = cfg::OFF_P0 * 8, PG_BYTES = cfg::OFF_P1 * 8;
         StatsLayout L(d, K);
         double *out = p.part + (int64_t)blockIdx.x * L.len;
 
@@ -339,46 +351,42 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             }
             const unsigned char *wq = smb + (lh == 0 ? P0_BYTES : PG_BYTES) + ((l4 & 1) * NCOL + l15) * 16;
             constexpr int PSTRIDE = 2 * NCOL * 16;  // bytes between digit planes
-#pragma unroll
-            for (int t = 0; t < NCT; ++t) {
-                // planes in three batches {0,1,2}, {3,4,5}, {6}: 24-bit pieces of the sums, each added to the int64
-                // accumulators on its own (twelve operand and twelve result registers in flight, not 28 + 28)
-                const unsigned char *wt = wq + t * 256;
-                {
-                    const i4_t b0 = *reinterpret_cast<const i4_t *>(wt), b1 = *reinterpret_cast<const i4_t *>(wt + PSTRIDE),
-                               b2 = *reinterpret_cast<const i4_t *>(wt + 2 * PSTRIDE);
-#pragma unroll
-                    for (int r = 0; r < RT; ++r) {
-                        i4_t d0, d1, d2;
-                        mfma_i8_x3(af[r], b0, b1, b2, d0, d1, d2);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)  // D row = 4 l4 + q (dim 16 r + 4 l4 + q), column l15
-                            accM[r][t][q] += (long long)((((d2[q] << 8) + d1[q]) << 8) + d0[q]);  // |.| < 2^30
+            // The planes go through in three batches per column tile -- {0,1,2}, {3,4,5}, {6}: 24-bit pieces of the sums,
+            // each added to the int64 accumulators on its own -- one block = one (column tile, batch, row tile).  The
+            // blocks are software-pipelined two deep: the MFMAs of block i+1 are issued before the sums of block i are
+            // folded, so the matrix pipe works while the integers are recombined (12 + 12 result registers in flight).
+            constexpr int NBLK = NCT * 3 * RT;
+            i4_t dd[2][3];
+            i4_t bb[3];
+            auto issue = [&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value, t = i / (3 * RT), batch = (i / RT) % 3, r = i % RT;
+                const unsigned char *wt = wq + t * 256 + 3 * batch * PSTRIDE;
+                if constexpr (r == 0) {  // the batch's B operands, shared by its four row tiles
+                    bb[0] = *reinterpret_cast<const i4_t *>(wt);
+                    if constexpr (batch < 2) {
+                        bb[1] = *reinterpret_cast<const i4_t *>(wt + PSTRIDE);
+                        bb[2] = *reinterpret_cast<const i4_t *>(wt + 2 * PSTRIDE);
                     }
                 }
-                {
-                    const i4_t b3 = *reinterpret_cast<const i4_t *>(wt + 3 * PSTRIDE), b4 = *reinterpret_cast<const i4_t *>(wt + 4 * PSTRIDE),
-                               b5 = *reinterpret_cast<const i4_t *>(wt + 5 * PSTRIDE);
+                if constexpr (batch < 2) mfma_i8_x3(af[r], bb[0], bb[1], bb[2], dd[i & 1][0], dd[i & 1][1], dd[i & 1][2]);
+                else mfma_i8_x1(af[r], bb[0], dd[i & 1][0]);
+            };
+            auto fold = [&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value, t = i / (3 * RT), batch = (i / RT) % 3, r = i % RT;
+                const i4_t *d3 = dd[i & 1];
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) {
-                        i4_t d3, d4, d5;
-                        mfma_i8_x3(af[r], b3, b4, b5, d3, d4, d5);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            accM[r][t][q] += (long long)((((d5[q] << 8) + d4[q]) << 8) + d3[q]) << 24;
-                    }
+                for (int q = 0; q < 4; ++q) {  // D row = 4 l4 + q (dim 16 r + 4 l4 + q), column l15
+                    if constexpr (batch == 0) accM[r][t][q] += (long long)((((d3[2][q] << 8) + d3[1][q]) << 8) + d3[0][q]);  // |.| < 2^30
+                    else if constexpr (batch == 1) accM[r][t][q] += (long long)((((d3[2][q] << 8) + d3[1][q]) << 8) + d3[0][q]) << 24;
+                    else accM[r][t][q] += (long long)d3[0][q] << 48;
                 }
-                {
-                    const i4_t b6 = *reinterpret_cast<const i4_t *>(wt + 6 * PSTRIDE);
-#pragma unroll
-                    for (int r = 0; r < RT; ++r) {
-                        i4_t d6;
-                        mfma_i8_x1(af[r], b6, d6);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) accM[r][t][q] += (long long)d6[q] << 48;
-                    }
-                }
-            }
+            };
+            issue(std::integral_constant<int, 0>{});
+            static_for<NBLK>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                if constexpr (i + 1 < NBLK) issue(std::integral_constant<int, i + 1>{});
+                fold(i_tag);
+            });
         };
 
         for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
@@ -388,18 +396,21 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             const bool last = tile + 1 == tile_end;
             const int slot_cur = rel % 3, slot_prev = (rel + 2) % 3;
             __syncthreads();  // front: P3(tile) done -> the tile's W rows are final
-            E8_STAMP(4)
+            E8_STAMP(5)
 #pragma unroll 1
             for (;;) {  // normally one trip
                 ++attempt;
                 const bool bad = !have_scale || digitise(lane, pending ? PG_BYTES : P0_BYTES);
                 if (bad && lane == 0) __hip_atomic_store(vstamp, attempt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 role_barrier(bbar, bbar_target, lane_entry);
-                E8_STAMP(5)
+                E8_STAMP(6)
                 const bool viol = __builtin_amdgcn_readfirstlane(__hip_atomic_load(vstamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == attempt;
                 // What is contracted now: a fitting tile completes its group (or is the last tile: alone); a tile that does
                 // not fit sends what is pending in alone, under the old exponents -- then (cold path) the integers leave
                 // for the partial, the exponents rise and the tile is cut again.
+                if (!viol) {  // every back wave has read the tile's rows for the last time: the front may overwrite them
+                    if (lane_entry == 0) __hip_atomic_fetch_add(digdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 const bool con = pending || (!viol && last);
                 if (con) {
                     contract(lane, !viol && pending, pending ? slot_prev : slot_cur, slot_cur);
@@ -417,19 +428,18 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 have_scale = 1;
                 role_barrier(bbar, bbar_target, lane_entry);
             }
-            E8_STAMP(6)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane_entry == 0) __hip_atomic_fetch_add(bdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            E8_STAMP(7)
         }
         emit(lane_entry, flushed != 0, false);
 #ifdef PPCA_PHASE_TIMING
         if (p.dbg && tid == 256)
-            for (int i = 4; i < 8; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
+            for (int i = 5; i < 8; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
 #endif
         return;
     }
 
     // =============================================================== front role
+    if (E8_FRONT_PRIO) __builtin_amdgcn_s_setprio(E8_FRONT_PRIO);
     unsigned fbar_target = 0u;
     double mu[4];  // staging lane map: lane l holds dims 128 h + 2 l + e (element q = 2 h + e) of a row
 #pragma unroll
@@ -648,8 +658,9 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             group(qbA, false);  // digits {3,2}
             group(qbB, false);  // digits {1,0}
             E8_STAMP(0)
-            // [G | b] may still hold the previous tile's digit planes: wait until the back role has finished that tile
-            wait_counter(bdone, 4u * (unsigned)rel);
+            // [G | b] shares its buffer with the previous tile's W rows: wait until the back role has cut them (long done:
+            // the cut is the first thing the back does after the workgroup barrier)
+            wait_counter(digdone, 4u * (unsigned)rel);
             if (gram_wave) {
 #pragma unroll
                 for (int rt2 = 0; rt2 < 2; ++rt2)
@@ -685,9 +696,14 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             Posterior<K> post;
             double pm;
             int pe;
-            post.factor([&](int e) { return g0[e]; }, s2, pm, pe);
             double z[K], quad, zz;
-            post.solve([&](int a) { return g0[16 * NTP + a] + b1[a]; }, z, quad, zz);
+            post.load([&](int e) { return g0[e]; }, s2);
+#pragma unroll
+            for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a] + b1[a];
+            // the W rows go where [G | b] is: every front wave holds its operands before any of them writes a row
+            role_barrier(fbar, fbar_target, lane_entry);
+            post.factor_loaded(pm, pe);
+            post.solve_loaded(z, quad, zz);
             double trpart = 0.0;
             if constexpr (PAIRS) {
 #pragma unroll
@@ -770,11 +786,11 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
         // ------------------------------------------------------------ P1 of the next tile
         stage_tile(tile + 1, lane);
         role_barrier(fbar, fbar_target, lane_entry);
-        E8_STAMP(0)
+        E8_STAMP(4)
     }
 #ifdef PPCA_PHASE_TIMING
     if (p.dbg && tid == 0)
-        for (int i = 0; i < 4; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
+        for (int i = 0; i < 5; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
 #endif
 
     // ---------------------------------------------------------------- epilogue (front waves)

@@ -1823,6 +1823,24 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
     return hipSuccess;
 }
 
+// The Gram engine the generic pipeline would use for this model: *forced = 1 when the environment pins the fp64 form,
+// otherwise -1 and *flag_dev points at the guard flag (0 = int8-sliced, non-zero = fp64) the digit kernels just wrote.
+// ws: a workspace of generic_workspace_bytes(d, k, 1).
+hipError_t generic_gram_guard(int d, int k, const double *model, void *ws, hipStream_t s, const int **flag_dev, int *forced) {
+    if (!generic_i8()) {
+        *forced = 1;
+        return hipSuccess;
+    }
+    *forced = -1;
+    const int64_t kp = (int64_t)k * (k + 1) / 2;
+    GenWs W = carve(ws, d, k, 1);
+    hipLaunchKernelGGL(gen_rmin_kernel, dim3(1), dim3(256), 0, s, model, d, k, W.rmin, W.flags);
+    hipLaunchKernelGGL(gen_qdigits_kernel, dim3((unsigned)kp), dim3(256), 0, s, model, d, k, W.dpad, (int)kp, W.rmin, W.scaleQ, W.BtQ,
+                       W.flags);
+    *flag_dev = W.flags;
+    return hipGetLastError();
+}
+
 hipError_t generic_em_accumulate(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k,
                                  const double *model, double *stats, void *ws, int n_cu, hipStream_t s) {
     return generic_run(X, ldx, w, n, d, k, model, true, stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0,

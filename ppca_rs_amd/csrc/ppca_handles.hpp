@@ -74,6 +74,18 @@ struct ppca_ctx {
     // the kernels): 0 llk, 1 u, 2 lse, 3 log posteriors, 4 component weights, 5 row list, 6 block counts
     BufRef mix[7];
     size_t mix_cap[7] = {0, 0, 0, 0, 0, 0, 0};
+    BufRef mixpack;  // one-call mixture step: [component statistics ... | weight sums | llk] (the all-reduce(SUM) buffer)
+    size_t mixpack_cap = 0;
+    BufRef mixaux;   // ... its small device-side vectors: maxima / shifts, new log-weights + llk
+    size_t mixaux_cap = 0;
+    // pinned host memory: a small staging area for asynchronous uploads / downloads of a few values, and the two chunk
+    // buffers of the pipelined device-to-host copy (ppca_dataset_to_host, ppca_infer); allocated on first use
+    void *hstage = nullptr;
+    size_t hstage_cap = 0;
+    void *pin[2] = {nullptr, nullptr};
+    size_t pin_cap = 0;
+    BufRef canon[2];  // device-side chunk buffers of the canonicalising copy (non-finite -> NaN)
+    size_t canon_cap[2] = {0, 0};
 };
 
 struct ppca_dataset {
@@ -92,6 +104,8 @@ struct ppca_model {
     double *p() const { return static_cast<double *>(buf->p); }
 };
 
+ppca_ctx *ppca_comm_context(ppca_comm *comm);  // ppca_comm.hip (internal)
+
 namespace ppca_host {
 // Records the message of the failure for ppca_last_error() on this thread and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -99,6 +113,10 @@ int dev_alloc(size_t bytes, BufRef *out);
 BufRef dev_borrow(const void *p);
 int ensure(BufRef &b, size_t &cap, size_t bytes);
 int use_device(const ppca_ctx *ctx);
+int ensure_hstage(ppca_ctx *ctx, size_t bytes);
+// PPCAMix::iterate_with_prior over the context's rows (comm nullable: one row shard of several), ppca_capi.hip
+int mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppca_model *const *models_in, const double *log_weights_in,
+                int32_t nm, const ppca_prior *prior, ppca_model *const *models_out, double *log_weights_out, double *llk_in);
 // dev_alloc draws from (and its buffers return to) the innermost scope's pool on this thread
 struct PoolScope {
     std::shared_ptr<DevPool> *prev;

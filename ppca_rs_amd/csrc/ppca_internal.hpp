@@ -87,6 +87,7 @@ hipError_t generic_em_accumulate(const double *X, int64_t ldx, const double *w, 
 hipError_t generic_post(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k, const double *model,
                         double *scal8, double *llks, double *states, double *covs, double *recon, int recon_mode,
                         void *ws, int n_cu, hipStream_t s);
+hipError_t generic_gram_guard(int d, int k, const double *model, void *ws, hipStream_t s, const int **flag_dev, int *forced);
 hipError_t generic_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
                             int has_ig, double alpha, double beta, int n_cu, hipStream_t s);
 
@@ -101,7 +102,10 @@ hipError_t launch_reduce_max(const double *v, int64_t n, double *out_scalar, dou
 // out[i] = exp(v[i] - *max_dev)
 hipError_t launch_exp_shift(const double *v, const double *max_dev, int64_t n, double *out, hipStream_t s);
 hipError_t launch_reduce_sum(const double *v, const double *w, int64_t n, double *out_scalar, double *work,
-                             hipStream_t s);
+                             hipStream_t s, const int *n_dev = nullptr);  // n_dev: the element count lives on the device (n = upper bound)
+hipError_t launch_mix_shift(double *mx, int nm, hipStream_t s);  // non-finite maxima -> 0 (mix.rs:312-323), in place
+// out[0 .. nm) = log_softmax(ln sums + shift) (mix.rs:324-325, :335), out[nm] = *llk (nullable)
+hipError_t launch_mix_logweights(const double *sums, const double *shift, const double *llk, int nm, double *out, hipStream_t s);
 // rows[0 .. m) = ascending indices i with exp(v[i] - *shift_dev) > 0, wout[0 .. m) those weights, counts[select_blocks(n)] = m
 // (counts: select_blocks(n) + 1 ints of scratch).
 hipError_t launch_select_positive(const double *v, const double *shift_dev, int64_t n, int *counts, int *rows, double *wout,

@@ -1464,9 +1464,10 @@ __global__ void mix_posteriors_kernel(const double *llk, const double *logw, con
 }
 
 template <bool MAX>
-__global__ void reduce_stage_kernel(const double *v, const double *w, int64_t n, double *out) {
+__global__ void reduce_stage_kernel(const double *v, const double *w, int64_t n, double *out, const int *n_dev = nullptr) {
     __shared__ double red[256];
     const int tid = threadIdx.x;
+    if (n_dev) n = *n_dev;  // (the count was produced on the device; the grid is sized for an upper bound)
     double acc = MAX ? -INFINITY : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
         double x = v[i];
@@ -1611,16 +1612,19 @@ void fused_qtab_layout(void *base, PassArgs &a) {  // [64 scales | 8 doubles of 
     a.qtab = reinterpret_cast<signed char *>(a.qscale + 72);
 }
 
-// Gram engine of the 4-wave passes: 0 = int8-sliced MFMA behind the dynamic-range guard, with the fp64-MFMA
-// instantiation as its on-device fallback (default); 1 = fp64 MFMA always (PPCA_GRAM_FP64=1);
-// 2 = int8 without the guard (PPCA_GRAM_GUARD=0: measurements only).
+// Gram engine of the fused passes: 0 = int8-sliced MFMA behind the dynamic-range guard, with the fp64-MFMA instantiation
+// as its on-device fallback (default); 1 = fp64 MFMA always (PPCA_GRAM_FP64=1: a safe choice, so a run-time switch);
+// 2 = int8 WITHOUT the guard -- only in builds compiled with -DPPCA_NO_GRAM_GUARD (measurements; never a run-time
+// switch: it would silently disable a parity guard).
 static int gram_mode() {
     static const int v = [] {
         const char *e = getenv("PPCA_GRAM_FP64");
         if (e && atoi(e) == 1) return 1;
-        const char *g = getenv("PPCA_GRAM_GUARD");
-        if (g && atoi(g) == 0) return 2;
+#ifdef PPCA_NO_GRAM_GUARD
+        return 2;
+#else
         return 0;
+#endif
     }();
     return v;
 }
@@ -1823,19 +1827,51 @@ hipError_t launch_reduce_max(const double *v, int64_t n, double *out_scalar, dou
     int blocks = (int)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((reduce_stage_kernel<true>), dim3(blocks), dim3(256), 0, s, v, (const double *)nullptr, n, work);
+    hipLaunchKernelGGL((reduce_stage_kernel<true>), dim3(blocks), dim3(256), 0, s, v, (const double *)nullptr, n, work, (const int *)nullptr);
     hipLaunchKernelGGL((reduce_stage_kernel<true>), dim3(1), dim3(256), 0, s, work, (const double *)nullptr,
-                       (int64_t)blocks, out_scalar);
+                       (int64_t)blocks, out_scalar, (const int *)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_reduce_sum(const double *v, const double *w, int64_t n, double *out_scalar, double *work,
-                             hipStream_t s) {
+                             hipStream_t s, const int *n_dev) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((reduce_stage_kernel<false>), dim3(blocks), dim3(256), 0, s, v, w, n, work);
+    hipLaunchKernelGGL((reduce_stage_kernel<false>), dim3(blocks), dim3(256), 0, s, v, w, n, work, n_dev);
     hipLaunchKernelGGL((reduce_stage_kernel<false>), dim3(1), dim3(256), 0, s, work, (const double *)nullptr,
-                       (int64_t)blocks, out_scalar);
+                       (int64_t)blocks, out_scalar, (const int *)nullptr);
+    return hipGetLastError();
+}
+
+// shifts of the mixture's component weights (mix.rs:312-323): a maximum that is not finite (no sample with a finite
+// ln w + log r: an empty shard set, or all weights zero) becomes 0 -- on the device, after the all-reduce(MAX)
+__global__ void mix_shift_kernel(double *mx, int nm) {
+    const int c = threadIdx.x;
+    if (c < nm) {
+        const double v = mx[c];
+        mx[c] = (v - v == 0.0) ? v : 0.0;
+    }
+}
+hipError_t launch_mix_shift(double *mx, int nm, hipStream_t s) {
+    hipLaunchKernelGGL(mix_shift_kernel, dim3(1), dim3(256), 0, s, mx, nm);
+    return hipGetLastError();
+}
+// new log-weights (mix.rs:324-325, :335): logsum_c = ln(sum_c) + shift_c, then robust_log_softmax (mix.rs:14-18); one
+// workgroup; out[0 .. nm) the log-weights, out[nm] = *llk (so that ONE copy brings both to the host)
+__global__ void mix_logweights_kernel(const double *sums, const double *shift, const double *llk, int nm, double *out) {
+    __shared__ double ls[256];
+    const int c = threadIdx.x;
+    ls[c] = c < nm ? log(sums[c]) + shift[c] : -INFINITY;
+    __syncthreads();
+    double mx = -INFINITY;
+    for (int i = 0; i < nm; ++i) mx = fmax(mx, ls[i]);  // (every thread the same order: deterministic)
+    double sm = 0.0;
+    for (int i = 0; i < nm; ++i) sm += exp(ls[i] - mx);
+    if (c < nm) out[c] = ls[c] - mx - log(sm);
+    if (c == 0) out[nm] = llk ? *llk : 0.0;
+}
+hipError_t launch_mix_logweights(const double *sums, const double *shift, const double *llk, int nm, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(mix_logweights_kernel, dim3(1), dim3(256), 0, s, sums, shift, llk, nm, out);
     return hipGetLastError();
 }
 // Posterior-weighted accumulation over mixture components (mix.rs:404-423, :447-461, :489-505):

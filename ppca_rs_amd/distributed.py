@@ -90,14 +90,39 @@ class Communicator:
 
     @classmethod
     def from_torch(cls, ctx: _lib.Context, group=None) -> "Communicator":
+        """Collective over the process group, failures included: rank 0's unique id -- or the reason it could not make
+        one (librccl missing, bound to another HIP runtime) -- is what gets broadcast, and after ncclCommInitRank every
+        rank learns whether ALL ranks succeeded; on any failure every rank raises the same error after leaving the
+        collectives, so a caller's fallback (bench.py --collective auto) is taken by all of them together."""
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()):
             return cls(ctx, 1, 0, cls.unique_id())
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box = [("id", cls.unique_id())]
+            except Exception as e:  # noqa: BLE001
+                box = [("error", f"rank 0: {e}")]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(ctx, world, rank, box[0])
+        kind, payload = box[0]
+        comm, err = None, None
+        if kind == "id":
+            try:
+                comm = cls(ctx, world, rank, payload)
+            except Exception as e:  # noqa: BLE001
+                err = f"rank {rank}: {e}"
+        else:
+            err = payload
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=group)
+        errs = [e for e in errs if e]
+        if errs:
+            if comm is not None:
+                comm.close()
+            raise RuntimeError("library communicator unavailable: " + "; ".join(errs))
+        return comm
 
     def allreduce(self, ptr_dev: int, n: int, op: str = "sum") -> None:
         check(lib().ppca_comm_allreduce(self.h, C.c_void_p(ptr_dev), n, {"sum": 0, "max": 1}[op]))
@@ -194,21 +219,24 @@ class ShardedEM:
 
 # --------------------------------------------------------------------------- sharded mixture (BASELINE config 5)
 class _DeviceMixBackend:
-    """The per-shard pieces of one mixture EM step on this rank's GPU, through the C-ABI."""
+    """The per-shard pieces of one mixture EM step on this rank's GPU, through the C-ABI building blocks -- the form
+    used when the collective is torch.distributed's (no library communicator).  Components may differ in state size
+    (mix.rs:50-71): every component has its own statistics length and offset in the packed buffer."""
 
     def __init__(self, shard: Dataset, models, prior):
         import torch
 
         self.torch, self.shard, self.ctx, self.prior = torch, shard, shard._ctx, prior
-        self.d, self.k, self.nm = models[0].output_size, models[0].state_size, len(models)
+        self.d, self.nm = models[0].output_size, len(models)
+        self.ks = [m.state_size for m in models]
         self.cur = [m._device(self.ctx) for m in models]
         self._keep_models = list(models)
         self.n = len(shard)
-        self.L = stats_len(self.d, self.k)
+        self.Ls = [stats_len(self.d, k) for k in self.ks]
+        self.offs = np.concatenate([[0], np.cumsum(self.Ls)]).astype(np.int64)
         self.u = torch.empty(max(self.nm * self.n, 1), dtype=torch.float64, device="cuda")
         self.lse = torch.empty(max(self.n, 1), dtype=torch.float64, device="cuda")
-        self.wc = torch.empty(max(self.n, 1), dtype=torch.float64, device="cuda")
-        self.stats = torch.zeros(self.nm * self.L, dtype=torch.float64, device="cuda")
+        self.stats = torch.zeros(int(self.offs[-1]), dtype=torch.float64, device="cuda")
         self._pref, self._keep = _prior_ref(prior)
 
     def _arr(self):
@@ -235,8 +263,8 @@ class _DeviceMixBackend:
 
     def accumulate(self, c: int, shift: float):
         """weights exp(u_c - shift), their sum, and the component's weighted statistics (device tensor view); rows whose
-        weight is exactly zero are skipped by the pass (ppca_mix_component_stats)."""
-        view = self.stats[c * self.L:(c + 1) * self.L]
+        weight is below 2^-200 of the component's largest are dropped from the pass (ppca_mix_component_stats)."""
+        view = self.stats[int(self.offs[c]):int(self.offs[c + 1])]
         if self.n == 0:
             view.zero_()
             return 0.0, view
@@ -254,45 +282,83 @@ class _DeviceMixBackend:
 
     def finalize(self, c: int, packed) -> None:
         h = C.c_void_p()
-        check(lib().ppca_model_alloc(self.ctx.handle, self.d, self.k, C.byref(h)))
+        check(lib().ppca_model_alloc(self.ctx.handle, self.d, self.ks[c], C.byref(h)))
         new = _DevModel(h)
-        check(lib().ppca_em_finalize(self.ctx.handle, self.cur[c].h, C.c_void_p(packed.data_ptr() + 8 * c * self.L), self._pref, new.h))
+        check(lib().ppca_em_finalize(self.ctx.handle, self.cur[c].h, C.c_void_p(packed.data_ptr() + 8 * int(self.offs[c])),
+                                     self._pref, new.h))
         self.cur[c] = new
 
     def max_tensor(self, values):
         return self.torch.tensor(values, dtype=self.torch.float64, device="cuda")
 
     def models(self):
-        return [PPCAModel._from_device(m, self.ctx, self.d, self.k) for m in self.cur]
+        return [PPCAModel._from_device(m, self.ctx, self.d, k) for m, k in zip(self.cur, self.ks)]
 
 
 class ShardedMixEM:
-    """PPCAMix::iterate_with_prior (mix.rs:281-337) over row shards, one process per GPU.  Per step: local
-    responsibilities; all-reduce(MAX) of the K per-component maxima of ln w_i + log r_ic (:312-317 take the maximum
-    over ALL samples); per component the weights exp(. - max), their sum and the weighted statistics; ONE
-    all-reduce(SUM) of [K statistic buffers | K weight sums | llk]; identical finalisation and new log-weights
-    (:335) on every rank.  `backend` supplies the per-shard pieces (default: this rank's GPU through the C-ABI)."""
+    """PPCAMix::iterate_with_prior (mix.rs:281-337) over row shards, one process per GPU.
+
+    With `comm` (a Communicator) -- or on a single rank -- a step is ONE C-ABI call, ppca_mix_em_step_sharded /
+    ppca_mix_em_step: local responsibilities, all-reduce(MAX) of the K per-component maxima of ln w_i + log r_ic
+    (:312-317 take the maximum over ALL samples), the K gathered component passes, ONE all-reduce(SUM) of
+    [K statistic buffers | K weight sums | llk], identical finalisation and new log-weights (:335) on every rank --
+    enqueued on the context stream with the shifts computed on the device.
+
+    Without a communicator on several ranks (the collective is torch.distributed's: gloo in the CPU tests, or
+    `--collective torch`), or with an injected `backend` (the CPU stand-in of the tests), the same protocol is
+    orchestrated here from the C-ABI building blocks."""
 
     def __init__(self, shard, start, prior: Optional[Prior] = None, group=None, backend=None, comm=None):
         self.group = group
-        self.comm = comm  # a Communicator: both all-reduces run inside the library (ppca_comm_allreduce, RCCL)
+        self.comm = comm
         self.log_weights = np.array(start.log_weights, dtype=np.float64)
         self.nm = len(start.models)
-        self.backend = backend or _DeviceMixBackend(shard, start.models, prior)
+        self.backend = backend
+        self._one_call = backend is None and (comm is not None or not self._multi())
+        if self._one_call:
+            self.shard, self.ctx = shard, shard._ctx
+            self.d, self.ks = start.models[0].output_size, [m.state_size for m in start.models]
+            self._pref, self._keep = _prior_ref(prior)
+            self.cur, self.nxt = [], []
+            for m in start.models:  # two PRIVATE device models per component (ping-pong; the caller's stay untouched)
+                h = C.c_void_p()
+                check(lib().ppca_model_create(self.ctx.handle, self.d, m.state_size, m.isotropic_noise, ptr(m._c), ptr(m._mean),
+                                              C.byref(h)))
+                self.cur.append(_DevModel(h))
+                h = C.c_void_p()
+                check(lib().ppca_model_alloc(self.ctx.handle, self.d, m.state_size, C.byref(h)))
+                self.nxt.append(_DevModel(h))
+        elif backend is None:
+            self.backend = _DeviceMixBackend(shard, start.models, prior)
+
+    def _multi(self) -> bool:
+        import torch.distributed as dist
+
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def step(self) -> float:
         """One EM step; returns the mixture log-likelihood of the input mixture over ALL shards."""
+        if self._one_call:
+            arr_in = (C.c_void_p * self.nm)(*[m.h for m in self.cur])
+            arr_out = (C.c_void_p * self.nm)(*[m.h for m in self.nxt])
+            lw_out = np.empty(self.nm)
+            llk = C.c_double(0.0)
+            if self.comm is not None:
+                check(lib().ppca_mix_em_step_sharded(self.comm.h, self.shard._h, arr_in, ptr(self.log_weights), self.nm, self._pref,
+                                                     arr_out, ptr(lw_out), C.byref(llk)))
+            else:
+                check(lib().ppca_mix_em_step(self.ctx.handle, self.shard._h, arr_in, ptr(self.log_weights), self.nm, self._pref,
+                                             arr_out, ptr(lw_out), C.byref(llk)))
+            self.cur, self.nxt = self.nxt, self.cur
+            self.log_weights = lw_out
+            return llk.value
         import torch.distributed as dist
 
         be, nm = self.backend, self.nm
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        multi = self._multi()
         llk_local = be.responsibilities(self.log_weights)
         mx = be.max_tensor([be.local_max(c) for c in range(nm)])
-        if self.comm is not None:
-            be.torch.cuda.current_stream().synchronize()  # mx was filled on torch's stream, the collective runs on the library's
-            self.comm.allreduce(mx.data_ptr(), nm, "max")
-            self.comm.ctx.synchronize()
-        elif multi:
+        if multi:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
         mx = np.asarray(mx.cpu().numpy(), dtype=np.float64)
         shifts = np.where(np.isfinite(mx), mx, 0.0)
@@ -300,11 +366,7 @@ class ShardedMixEM:
         for c in range(nm):
             sums[c], _ = be.accumulate(c, float(shifts[c]))
         packed = be.pack(np.concatenate([sums, [llk_local]]))
-        if self.comm is not None:
-            be.torch.cuda.current_stream().synchronize()
-            self.comm.allreduce(packed.data_ptr(), packed.numel(), "sum")
-            self.comm.ctx.synchronize()
-        elif multi:
+        if multi:
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
         extras = be.unpack_extras(packed, nm + 1)
         for c in range(nm):
@@ -318,4 +380,6 @@ class ShardedMixEM:
     def mixture(self):
         from .api import PPCAMix
 
+        if self._one_call:
+            return PPCAMix([PPCAModel._from_device(m, self.ctx, self.d, k) for m, k in zip(self.cur, self.ks)], self.log_weights)
         return PPCAMix(self.backend.models(), self.log_weights)

@@ -17,7 +17,8 @@ if "--asm" in sys.argv:
         procs.append(subprocess.Popen(base + ["--offload-device-only", "-S", os.path.join(C, src), "-o", out], stderr=subprocess.DEVNULL))
 assert all(p.wait() == 0 for p in procs)
 capi = "/tmp/ppca_capi.dev.o" if "--timing" in sys.argv else os.path.join(C, "ppca_capi.o")
-out = os.path.join(ROOT, "ppca_rs_amd", "libppca_hip_dev.so")
+name = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--name=")]
+out = os.path.join(ROOT, "ppca_rs_amd", "libppca_hip_%s.so" % (name[0] if name else "dev"))
 subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out, "/tmp/ppca_kernels.dev.o", "/tmp/ppca_em8.dev.o", "/tmp/ppca_llk.dev.o",
                                   os.path.join(C, "ppca_generic.o"), os.path.join(C, "ppca_comm.o"), capi])
 print(out)
