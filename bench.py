@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Benchmark of the PPCA EM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, or self-launching)
 
 One "step" = one full EM iteration over the synthetic dataset (fused E-step + M-step
 statistics pass, one RCCL all-reduce of the packed statistics when N > 1, on-device
 finalisation into the next model), inputs resident in HBM.  Workload = BASELINE.json's
 metric configuration: N = 10M samples x d = 256 x state_size = 10, 30 % iid masking,
 sharded by contiguous row blocks over the ranks (total work fixed => strong scaling).
+`--config 5` runs BASELINE configuration 5 instead (mixture of K = 8 components, N = 5 M): one step = one
+PPCAMix EM iteration = ONE C-ABI call per rank (ppca_mix_em_step_sharded / ppca_mix_em_step).
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -15,6 +17,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -29,7 +33,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # gfx950 correction calibrated on a known byte count): profiles/r01/README.md
 PMC_BYTES_PER_SAMPLE = 2077.5
 FP64_PEAK_TFLOPS = 78.6  # fp64 vector = fp64 matrix spec (dense MFMA peak for f64)
-KERNEL_NAME = "ppca::pass_kernel<10, true, 4, true, false>"
+TRAFFIC_FILES = ("profiles/r03/traffic.json", "profiles/r02/traffic.json")
 
 
 def algorithmic_bytes_per_sample(d: int) -> float:
@@ -41,64 +45,211 @@ def algorithmic_flops_per_sample(d: int, k: int, m: float) -> float:
     return 4 * m * kp + 4 * m * k + 2 * d * k + 2 * k ** 3
 
 
+def cargo_probe() -> dict:
+    """record whether the reference's own toolchain exists on this box (it cannot build
+    here either way: no network for the crates)."""
+    path = shutil.which("cargo")
+    ver = None
+    if path:
+        try:
+            ver = subprocess.run([path, "--version"], capture_output=True, text=True, timeout=10).stdout.strip()
+        except Exception as e:  # noqa: BLE001
+            ver = f"error: {e}"
+    return {"cargo": path, "cargo_version": ver}
+
+
+def timed_calls(fn, warmup_left: int, min_calls: int = 3, budget_s: float = 30.0):
+    """Warm-up calls (the first one is also the feasibility probe of the caller), then >= min_calls timed calls
+    within the budget; returns the list of timed durations."""
+    for _ in range(warmup_left):
+        fn()
+    times = []
+    t_end = time.time() + budget_s
+    while len(times) < min_calls and (not times or time.time() < t_end):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return times
+
+
 def cpu_baseline(ds, start_model, n_total: int, d: int, k: int, rows: int):
-    """Times the oracle (literal restatement of the reference's rayon path, OpenMP) on a
-    bounded sample of the same workload, on this box's host cores."""
+    """Times the oracle (literal restatement of the reference's rayon path, OpenMP, all host cores) on a bounded
+    sample of the same workload.  Protocol of BASELINE.md section 4: N_cpu = 1 M rows unless one call takes more
+    than 20 s (then 100 000 rows, said so), 2 full warm-up iterations, >= 3 timed, median, scaled linearly in N."""
     from oracle import ppca_oracle as o
 
-    x = ds._slice(0, rows).numpy()
     c, mu, s = start_model.transform, start_model.mean, start_model.isotropic_noise
-    o.iterate(x[:256], s, c, mu)  # warm up (thread pool, page faults)
-    times = []
-    t_end = time.time() + 25.0
-    while len(times) < 3 and (not times or time.time() < t_end):
-        t0 = time.perf_counter()
+    note = ""
+    x = ds._slice(0, rows).numpy()
+    t0 = time.perf_counter()
+    o.iterate(x, s, c, mu)  # warm-up 1 of 2 = the feasibility probe
+    probe = time.perf_counter() - t0
+    if probe > 20.0 and rows > 100_000:
+        note = f"; one iterate() on {rows} rows took {probe:.1f} s (> 20 s): fell back to 100000 rows"
+        rows = 100_000
+        x = x[:rows]
         o.iterate(x, s, c, mu)
-        times.append(time.perf_counter() - t0)
+    times = timed_calls(lambda: o.iterate(x, s, c, mu), warmup_left=1)
     t = float(np.median(times))
     # second CPU number (SURVEY.md 8d): the honestly optimised one-sweep form of the statistics pass
-    o.fused_stats(x[:256], s, c, mu)
-    tf = []
-    while len(tf) < 3:
-        t0 = time.perf_counter()
-        o.fused_stats(x, s, c, mu)
-        tf.append(time.perf_counter() - t0)
+    tf = timed_calls(lambda: o.fused_stats(x, s, c, mu), warmup_left=2, budget_s=15.0)
     tfm = float(np.median(tf))
-    return {
+    out = {
         "value": 1.0 / (t * n_total / rows),
         "unit": "EM iters/sec",
         "cores": o.num_threads(),
         "kind": "port",
-        "sample": f"{rows} of {n_total} rows of the same dataset, {len(times)} timed iterate() calls "
-                  f"(median {t:.3f} s), scaled linearly in N",
+        "sample": f"{rows} of {n_total} rows of the same dataset, 2 warm-up + {len(times)} timed iterate() calls "
+                  f"(median {t:.3f} s), scaled linearly in N{note}",
         "samples_per_sec": rows / t,
         "optimised_port": {"value": 1.0 / (tfm * n_total / rows), "unit": "EM iters/sec", "cores": o.num_threads(),
                            "what": "oracle.fused_stats: one OpenMP sweep, table Gram + Cholesky, thread-private statistics "
                                    f"(median {tfm:.3f} s on the same {rows} rows, scaled linearly in N; finalisation excluded)"},
     }
+    out.update(cargo_probe())
+    return out
+
+
+def cpu_baseline_mix(x: np.ndarray, start, n_total: int):
+    """Config 5: oracle.mix_iterate (literal PPCAMix::iterate_with_prior, mix.rs:281-337) on a bounded sample."""
+    from oracle import ppca_oracle as o
+
+    sig = [m.isotropic_noise for m in start.models]
+    cs = [m.transform for m in start.models]
+    ms = [m.mean for m in start.models]
+    lw = start.log_weights
+    rows = x.shape[0]
+    times = timed_calls(lambda: o.mix_iterate(x, sig, cs, ms, lw), warmup_left=1, min_calls=2, budget_s=30.0)
+    t = float(np.median(times))
+    out = {
+        "value": 1.0 / (t * n_total / rows),
+        "unit": "mixture EM iters/sec",
+        "cores": o.num_threads(),
+        "kind": "port",
+        "sample": f"{rows} of {n_total} rows of the same dataset, 1 warm-up + {len(times)} timed mix_iterate() calls "
+                  f"(median {t:.3f} s), scaled linearly in N",
+        "samples_per_sec": rows / t,
+    }
+    out.update(cargo_probe())
+    return out
+
+
+def self_launch(args) -> int:
+    """Plain `python bench.py --gpus N`: start N fresh ranks (one per GPU) as CHILD processes and relay rank 0's JSON
+    line.  Nothing in this process has touched torch or the GPU yet, and it never will (a process that has
+    initialised the GPU must not exec another program on this pool).  If any rank fails, the others are stopped and
+    that rank's stderr tail is what the caller sees, with a non-zero exit code."""
+    import socket
+    import tempfile
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tmp = tempfile.mkdtemp(prefix="ppca_bench_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        err = open(os.path.join(tmp, f"rank{r}.err"), "w")
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err), err))
+    def stop_children(signum=None, frame=None):  # never leave ranks behind when the launcher itself is stopped
+        for p, _ in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p, _ in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        if signum is not None:
+            raise SystemExit(128 + signum)
+
+    import signal
+
+    signal.signal(signal.SIGTERM, stop_children)
+    signal.signal(signal.SIGINT, stop_children)
+    failed = None
+    pending = set(range(args.gpus))
+    out0 = b""
+    while pending and failed is None:
+        for r in sorted(pending):
+            p, _ = procs[r]
+            if r == 0 and p.stdout is not None:
+                pass  # (read at the end: one JSON line fits the pipe buffer)
+            rc = p.poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+                    break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in pending:
+            procs[r][0].terminate()
+        for r in pending:
+            try:
+                procs[r][0].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r][0].kill()
+    if procs[0][0].stdout is not None:
+        out0 = procs[0][0].stdout.read()
+    for _, err in procs:
+        err.close()
+    if failed is not None:
+        r, rc = failed
+        with open(os.path.join(tmp, f"rank{r}.err")) as fh:
+            tail = fh.read()[-4000:]
+        print(f"[bench] rank {r} of {args.gpus} exited with code {rc}; its stderr tail:\n{tail}", file=sys.stderr)
+        return rc if rc > 0 else 1
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    for r in range(args.gpus):  # the ranks' stderr (library notes) goes to ours
+        with open(os.path.join(tmp, f"rank{r}.err")) as fh:
+            txt = fh.read()
+        if txt.strip():
+            sys.stderr.write(txt)
+    shutil.rmtree(tmp, ignore_errors=True)
+    return 0
+
+
+def traffic_from_profiles(rows_local: int):
+    for rel in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as fh:
+                tj = json.load(fh)
+            return tj["hbm_bytes_per_sample"] * rows_local, f"{rel} (commit {tj.get('commit')}, N = {tj.get('n_samples')}, kernel {tj.get('kernel')})"
+        except (OSError, KeyError, ValueError):
+            continue
+    return PMC_BYTES_PER_SAMPLE * rows_local, "profiles/r01/README.md (N = 2 M, round-1 build)"
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--n", "--samples", dest="n", type=int, default=10_000_000)
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mask", type=float, default=0.3)
-    ap.add_argument("--cpu-rows", type=int, default=100_000)
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU tests)")
     ap.add_argument("--collective", default="auto", choices=["auto", "capi", "torch"],
                     help="who runs the all-reduce of the statistics: the library's own RCCL communicator behind the "
                          "C-ABI (capi), torch.distributed (torch), or capi with torch as the fallback if the "
                          "communicator cannot be created (auto)")
+    ap.add_argument("--gram", default="auto", choices=["auto", "fp64"],
+                    help="Gram engine of the fused passes: the int8-sliced MFMA behind its dynamic-range guard (auto), or "
+                         "the guard's fallback engine, the fp64 MFMA, always (fp64; = PPCA_GRAM_FP64=1)")
     ap.add_argument("--dump-model", default=None, help="rank 0 writes the final model to this .npz (tests)")
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="a BASELINE.json configuration by number (1: toy 10k x 32 x 4 unmasked; 2: 1M x 256 x 10; 3: the "
-                         "headline 10M x 256 x 10 = the default; 4: 2M x 1024 x 64, 50%% block-masked, generic pipeline); "
-                         "0 = take --n/--d/--k/--mask as given")
+                         "headline 10M x 256 x 10 = the default; 4: 2M x 1024 x 64, 50%% block-masked, generic pipeline; "
+                         "5: mixture of 8 components, 5M x 256 x 10); 0 = take --n/--d/--k/--mask as given")
+    ap.add_argument("--components", type=int, default=8, help="config 5: number of mixture components")
     args = ap.parse_args()
     mask_kind, mask_run = 0, 0
     if args.config == 1:
@@ -111,23 +262,23 @@ def main() -> None:
         args.n, args.d, args.k, args.mask = 2_000_000, 1024, 64, 0.5
         mask_kind, mask_run = 1, 512  # one cyclic run of d/2 masked dims per sample
         args.cpu_rows = min(args.cpu_rows, 4000)  # (the literal port needs ~3 ms per sample at this shape)
+    elif args.config == 5:
+        if args.n == 10_000_000:
+            args.n = 5_000_000
+        args.d, args.k, args.mask = 256, 10, 0.3
+    mixture = args.config == 5
+    if args.steps is None:
+        args.steps = 11 if mixture else 20   # config 5: iterations 10..20 (the converged regime) are the timed ones
+    if args.warmup is None:
+        args.warmup = 9 if mixture else 3    # ... after iterations 1..9, of which the first three are reported too
+    if args.gram == "fp64":
+        os.environ["PPCA_GRAM_FP64"] = "1"  # read once by the library when it loads (below)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # Plain `python bench.py --gpus N`: start N fresh ranks (one per GPU) as CHILD processes and relay rank 0's
-        # JSON line.  Nothing in this process has touched torch or the GPU yet, and it never will.
-        import socket
-        import subprocess
-
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+        raise SystemExit(self_launch(args))
     if world != args.gpus:
         args.gpus = world
 
@@ -143,30 +294,54 @@ def main() -> None:
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    import ctypes as C
+
     import ppca_rs_amd as P
     from ppca_rs_amd import _lib
-    from ppca_rs_amd.distributed import ShardedEM, shard_bounds
+    from ppca_rs_amd.distributed import ShardedEM, ShardedMixEM, shard_bounds
 
     ctx = _lib.Context(dev_index)
     _lib.set_default_context(ctx)
 
     n, d, k = args.n, args.d, args.k
-    # SURVEY.md 8(d) seeds: C_true 1011, mean_true 1012, data 1013; start model 2011
-    c_true = np.random.default_rng(1011).standard_normal((d, k))
-    mean_true = np.random.default_rng(1012).standard_normal(d)
-    truth = P.PPCAModel(0.1, c_true, mean_true)
     a, b = shard_bounds(n, world, rank)
-    spec = _lib.SynthSpec(a, b - a, d, k, 0.1, args.mask, mask_kind, mask_run, 1013,
-                          truth._c.ctypes.data_as(_lib.c_double_p), truth._mean.ctypes.data_as(_lib.c_double_p))
-    import ctypes as C
 
-    h = C.c_void_p()
-    _lib.check(_lib.lib().ppca_dataset_generate(ctx.handle, C.byref(spec), C.byref(h)))
-    shard = P.Dataset._wrap(h, ctx)
-    c0 = np.random.default_rng(2011).standard_normal(d * k).reshape((k, d)).T.copy()
-    start = P.PPCAModel(1.0, c0, np.zeros(d))  # as PPCAModel::init (ppca_model.rs:51-70)
+    def generate(c_true, mean_true, row_offset, n_rows, seed):
+        truth = P.PPCAModel(0.1, c_true, mean_true)
+        spec = _lib.SynthSpec(row_offset, n_rows, d, k, 0.1, args.mask, mask_kind, mask_run, seed,
+                              truth._c.ctypes.data_as(_lib.c_double_p), truth._mean.ctypes.data_as(_lib.c_double_p))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ppca_dataset_generate(ctx.handle, C.byref(spec), C.byref(h)))
+        return P.Dataset._wrap(h, ctx)
 
-    # The one collective of the path.  Default: the library's own RCCL communicator (ppca_comm, behind the C-ABI);
+    if mixture:
+        # K ground-truth components, mean_c ~ N(0, 3^2), C_c ~ N(0, 1), sigma 0.1, uniform
+        # weights; rows keyed by GLOBAL index (block b of 65536 rows belongs to component b % K), so every rank's
+        # contiguous shard holds all components and the data do not depend on the number of ranks
+        nm, blk = args.components, 65536
+        comps = [(np.random.default_rng(1051 + 10 * c).standard_normal((d, k)), 3.0 * np.random.default_rng(1052 + 10 * c).standard_normal(d))
+                 for c in range(nm)]
+        parts = []
+        for b0 in range((a // blk) * blk, b, blk):
+            lo, hi = max(a, b0), min(b, b0 + blk)
+            if hi > lo:
+                c = (b0 // blk) % nm
+                parts.append(generate(comps[c][0], comps[c][1], lo, hi - lo, 1053))
+        shard = P.Dataset.concat(parts) if len(parts) != 1 else parts[0]
+        del parts
+        ctx.trim()
+        # start = K random models, log-weights 0 (PPCAMix::init mix.rs:76-83); seeded, identical on every rank
+        start = P.PPCAMix([P.PPCAModel(1.0, np.random.default_rng(2051 + c).standard_normal(d * k).reshape((k, d)).T.copy(), np.zeros(d))
+                           for c in range(nm)], np.zeros(nm))
+    else:
+        # SURVEY.md 8(d) seeds: C_true 1011, mean_true 1012, data 1013; start model 2011
+        c_true = np.random.default_rng(1011).standard_normal((d, k))
+        mean_true = np.random.default_rng(1012).standard_normal(d)
+        shard = generate(c_true, mean_true, a, b - a, 1013)
+        c0 = np.random.default_rng(2011).standard_normal(d * k).reshape((k, d)).T.copy()
+        start = P.PPCAModel(1.0, c0, np.zeros(d))  # as PPCAModel::init (ppca_model.rs:51-70)
+
+    # The collective(s) of the path.  Default: the library's own RCCL communicator (ppca_comm, behind the C-ABI);
     # torch.distributed carries only the rendezvous (unique id), the barrier and the max-over-ranks of the clock.
     comm, collective = None, "none (single rank)"
     if world > 1:
@@ -175,19 +350,15 @@ def main() -> None:
             from ppca_rs_amd.distributed import Communicator
 
             try:
-                comm = Communicator.from_torch(ctx)
-                collective = "ppca_em_step_sharded: " + Communicator.backend()
-            except Exception as e:  # noqa: BLE001
+                comm = Communicator.from_torch(ctx)  # collective, failures included: every rank takes the same branch
+                n_ranks = int(_lib.lib().ppca_comm_n_ranks(comm.h))
+                assert n_ranks == world, f"rank {rank}: communicator spans {n_ranks} ranks, WORLD_SIZE is {world}"
+                collective = ("ppca_mix_em_step_sharded: " if mixture else "ppca_em_step_sharded: ") + Communicator.backend() + f", {n_ranks} ranks"
+            except RuntimeError as e:
                 if args.collective == "capi":
                     raise
                 print(f"[bench rank {rank}] C-ABI communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
-            # all ranks must agree on the path
-            flag = torch.tensor([1 if comm is not None else 0], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and comm is not None:
-                comm.close()
-                comm, collective = None, f"torch.distributed all_reduce ({args.backend})"
-    em = ShardedEM(shard, start, comm=comm)
+    em = ShardedMixEM(shard, start, comm=comm) if mixture else ShardedEM(shard, start, comm=comm)
 
     def sync():
         torch.cuda.synchronize()
@@ -195,23 +366,40 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        em.step()
+    first_iters = []
+    llk_trace = []
+    for i in range(args.warmup):
+        if mixture and i < 3:  # the soft-responsibility regime right after PPCAMix.init: timed on the side
+            sync()
+            t0 = time.perf_counter()
+            llk_trace.append(em.step())
+            sync()
+            first_iters.append(time.perf_counter() - t0)
+        else:
+            v = em.step()
+            if mixture:
+                llk_trace.append(v)
     sync()
     ctx.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        em.step()
+        v = em.step()
+        if mixture:
+            llk_trace.append(v)
     sync()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = ctx.kernel_time(reset=True)
     ctx.enable_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed] + first_iters, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    llk_last = em.llk_of_previous()
-    if args.dump_model and rank == 0:
+        elapsed = float(t[0].item())
+        first_iters = [float(x) for x in t[1:].tolist()]
+    if mixture:
+        llk_last = llk_trace[-1] if llk_trace else float("nan")
+    else:
+        llk_last = em.llk_of_previous()
+    if args.dump_model and rank == 0 and not mixture:
         fm = em.model()
         np.savez(args.dump_model, sigma=fm.isotropic_noise, transform=fm.transform, mean=fm.mean, llk=llk_last)
 
@@ -219,25 +407,50 @@ def main() -> None:
         ms_per_step = 1e3 * elapsed / args.steps
         iters_per_s = args.steps / elapsed
         rows_local = b - a
-        kern_avg_ms = kern_ms / max(launches, 1)
-        bytes_launch = rows_local * algorithmic_bytes_per_sample(d)
-        flops_launch = rows_local * algorithmic_flops_per_sample(d, k, d * (1.0 - args.mask))
-        achieved = bytes_launch / (kern_avg_ms * 1e-3) / 1e9
-        t_kernel = kern_avg_ms * 1e-3
-        tflops = flops_launch / t_kernel / 1e12
-        gbs = achieved
-        fp64_bound = flops_launch / (FP64_PEAK_TFLOPS * 1e12) >= bytes_launch / (HBM_PEAK_GBS * 1e9)
-        traffic, traffic_src = None, None
-        if (d, k) == (256, 10) and mask_kind == 0:
-            # HBM bytes per sample of the dominant kernel by rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950
-            # correction), measured at the headline size and committed with the commit it was measured on
-            try:
-                with open(os.path.join(ROOT, "profiles", "r02", "traffic.json")) as fh:
-                    tj = json.load(fh)
-                traffic = tj["hbm_bytes_per_sample"] * rows_local
-                traffic_src = f"profiles/r02/traffic.json (commit {tj.get('commit')}, N = {tj.get('n_samples')})"
-            except (OSError, KeyError, ValueError):
-                traffic, traffic_src = PMC_BYTES_PER_SAMPLE * rows_local, "profiles/r01/README.md (N = 2 M, round-1 build)"
+        m_obs = d * (1.0 - args.mask)
+        # which Gram engine the fused passes ran on (decided on the device per model; the start model is representative
+        # of the run's: unit-scale C, sigma 1 -> 0.1)
+        eng = C.c_int32(-1)
+        probe = start.models[0] if mixture else start
+        _lib.check(_lib.lib().ppca_gram_engine(ctx.handle, probe._device(ctx).h, C.byref(eng)))
+        gram_engine = {0: "int8-sliced MFMA (exact integer accumulation) behind the dynamic-range guard", 1: "fp64 MFMA"}.get(eng.value, "?")
+        fused = _lib.lib().ppca_path_kind(d, k) == 1
+        if mixture:
+            nm = args.components
+            # the mixture is reported against the ONE-pass byte figure (X read once per iteration) and
+            # K x the flops of a k = 10 EM iteration (what the reference's K weighted iterate() calls perform; the
+            # responsibility-sparse component passes skip the rows whose weight is below 2^-200 of the component's largest)
+            bytes_step = rows_local * algorithmic_bytes_per_sample(d)
+            flops_step = nm * rows_local * algorithmic_flops_per_sample(d, k, m_obs)
+            t_step = elapsed / args.steps
+            tflops, gbs = flops_step / t_step / 1e12, bytes_step / t_step / 1e9
+            fp64_bound = flops_step / (FP64_PEAK_TFLOPS * 1e12) >= bytes_step / (HBM_PEAK_GBS * 1e9)
+            kernel_name = (f"one mixture EM iteration = {nm} llk2_kernel<{k}> sweeps + {nm} gathered em8_kernel<{k}, true> passes + "
+                           "finalisations (timed as one region: ONE C-ABI call)")
+            kern_avg_ms, launches_rep = 1e3 * t_step, args.steps
+            traffic, traffic_src = None, None
+        else:
+            kern_avg_ms = kern_ms / max(launches, 1)
+            launches_rep = launches
+            bytes_step = rows_local * algorithmic_bytes_per_sample(d)
+            flops_step = rows_local * algorithmic_flops_per_sample(d, k, m_obs)
+            t_kernel = kern_avg_ms * 1e-3
+            tflops, gbs = flops_step / t_kernel / 1e12, bytes_step / t_kernel / 1e9
+            fp64_bound = flops_step / (FP64_PEAK_TFLOPS * 1e12) >= bytes_step / (HBM_PEAK_GBS * 1e9)
+            traffic, traffic_src = None, None
+            if (d, k) == (256, 10) and mask_kind == 0:
+                # HBM bytes per sample of the dominant kernel by rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950
+                # correction), measured at the headline size and committed with the commit it was measured on
+                traffic, traffic_src = traffic_from_profiles(rows_local)
+            if fused:
+                if eng.value == 1:
+                    kernel_name = f"ppca::pass_kernel<{k}, true, 4, false, false>"  # the guard's fallback engine
+                elif os.environ.get("PPCA_EM8") == "0":
+                    kernel_name = f"ppca::pass_kernel<{k}, true, 4, true, false>"
+                else:
+                    kernel_name = f"ppca::em8_kernel<{k}, false>"
+            else:
+                kernel_name = "generic split pipeline (all kernels of one pass, timed as one region)"
         roofline = {
             "bound": "mfma" if fp64_bound else "hbm",
             "achieved": tflops if fp64_bound else gbs,
@@ -247,12 +460,11 @@ def main() -> None:
             "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
             "traffic_source": traffic_src,
-            "kernel": KERNEL_NAME if (d, k) == (256, 10) else ("ppca::pass_kernel<k, true, 4, true>" if _lib.lib().ppca_path_kind(d, k) == 1
-                                                               else "generic split pipeline (all kernels of one pass, timed as one region)"),
+            "kernel": kernel_name,
             "kernel_avg_ms": kern_avg_ms,
-            "kernel_launches": launches,
-            "algorithmic_flops_per_launch": flops_launch,
-            "algorithmic_bytes_per_launch": bytes_launch,
+            "kernel_launches": launches_rep,
+            "algorithmic_flops_per_launch": flops_step,
+            "algorithmic_bytes_per_launch": bytes_step,
             "fp64_achieved_tflops": tflops,
             "fp64_peak_tflops": FP64_PEAK_TFLOPS,
             "fp64_frac": tflops / FP64_PEAK_TFLOPS,
@@ -262,10 +474,22 @@ def main() -> None:
             "note": "bound = the larger of (algorithmic bytes / HBM peak) and (algorithmic fp64 flops / dense fp64 MFMA peak) "
                     "per sample (SURVEY.md 8d): 0.261 ns vs 0.687 ns at d=256, k=10, so the fp64 pipe; hbm_* = the other one",
         }
+        if mixture:
+            workload = (f"PPCA mixture EM, {args.components} components, N={n} samples x d={d}, state_size={k}, "
+                        f"{int(100 * args.mask)}% iid masked, {world} contiguous row shard(s); per step one all-reduce(MAX) of "
+                        f"{args.components} f64 and one all-reduce(SUM) of {args.components * _lib.lib().ppca_stats_len(d, k) + args.components + 1} f64")
+            metric = "mixture EM iters/sec at K=8 components, N=5M d=256 k=10, 30% masked (BASELINE config 5)"
+            unit = "mixture EM iters/sec"
+        else:
+            workload = (f"PPCA EM, N={n} samples x d={d}, state_size={k}, {int(100 * args.mask)}% "
+                        f"{'block' if mask_kind else 'iid'} masked, "
+                        f"{world} contiguous row shard(s), one all-reduce of {_lib.lib().ppca_stats_len(d, k)} f64 per step")
+            metric = "EM iters/sec (and samples/sec/iter) at N=10M d=256 k=10, 30% masked"
+            unit = "EM iters/sec"
         out = {
-            "metric": "EM iters/sec (and samples/sec/iter) at N=10M d=256 k=10, 30% masked",
+            "metric": metric,
             "value": iters_per_s,
-            "unit": "EM iters/sec",
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -275,25 +499,39 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"PPCA EM, N={n} samples x d={d}, state_size={k}, {int(100 * args.mask)}% "
-                                   f"{'block' if mask_kind else 'iid'} masked, "
-                                   f"{world} contiguous row shard(s), one all-reduce of {_lib.lib().ppca_stats_len(d, k)} f64 per step",
+            "config": {"workload": workload,
                        "collective": collective,
                        "n_samples": n, "d": d, "state_size": k, "mask_prob": args.mask, "parallelism": f"dp{world}"},
             "samples_per_sec": n * iters_per_s,
             "llk_per_sample_last_input_model": llk_last / n,
+            "gram_engine": gram_engine,
             # the bound is max(bytes / HBM peak, flops / fp64 peak) per sample; at d = 256,
             # k = 10 that is the fp64 pipe (0.687 ns vs 0.261 ns), so the headline fraction is the fp64 one
             # and the HBM figures ride along.
             "roofline": roofline,
         }
+        if mixture:
+            out["config"]["n_components"] = args.components
+            out["regimes"] = {
+                "first_iterations": {"what": "iterations 1-3 from PPCAMix.init (soft responsibilities: every component pass sees every row)",
+                                     "ms_per_step": [1e3 * x for x in first_iters],
+                                     "value": (len(first_iters) / sum(first_iters)) if first_iters else None, "unit": unit},
+                "timed": {"what": f"iterations {args.warmup + 1}-{args.warmup + args.steps} (= `value`; from about iteration 10 a sample keeps weight in one component)",
+                          "ms_per_step": ms_per_step, "value": iters_per_s, "unit": unit},
+            }
+            out["llk_per_sample_trace"] = [v / n for v in llk_trace]
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(shard, start, n, d, k, min(args.cpu_rows, rows_local))
+            if mixture:
+                rows = min(20_000, rows_local)
+                out["cpu_baseline"] = cpu_baseline_mix(shard._slice(0, rows).numpy(), start, n)
+            else:
+                out["cpu_baseline"] = cpu_baseline(shard, start, n, d, k, min(args.cpu_rows, rows_local))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
-    em.close()
+    if not mixture:
+        em.close()
     if comm is not None:
         comm.close()
     if world > 1:

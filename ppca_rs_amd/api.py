@@ -367,10 +367,11 @@ class PPCAModel:
             raise ValueError("dataset is empty")  # assert!(!dataset.is_empty()) :52
         if state_size > 64:
             raise ValueError(f"state_size {state_size} is not supported: the MI355X kernels cover state sizes up to 64")
-        if state_size < 1:
-            # (the reference accepts 0 -- an isotropic Gaussian around the mean; the same model is state_size = 1 with a
-            #  zero transform column, which every pass here reproduces exactly: G = 0, z = 0, c stays 0)
-            raise ValueError("state_size must be at least 1 (state_size = 0 is a zero transform column at state_size = 1)")
+        if state_size < 0:
+            raise ValueError("state_size must be >= 0")
+        # state_size = 0 (an isotropic Gaussian around the mean, ppca_model.rs:51-70 with an empty transform; to_canonical
+        # :399-402) is accepted as the reference accepts it: the library carries it as ONE zero transform column, with
+        # which every pass reproduces the k = 0 model exactly (include/ppca_hip.h, ppca_model_create)
         d = dataset.output_size()
         rng = np.random.default_rng(seed)
         # DMatrix::from_vec is column-major (utils.rs:16-25)

@@ -12,7 +12,9 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ppca_handles.hpp"
@@ -180,11 +182,99 @@ int ppca_host::ensure_hstage(ppca_ctx *ctx, size_t bytes) {
     return PPCA_OK;
 }
 
+// ------------------------------------------------------------------ device -> host, pipelined
+// A pageable hipMemcpy of a large block comes back at ~12-25 GB/s (one staging thread, first-touch page faults of the
+// destination on that same thread).  Here the block leaves in 64 MB chunks: [canonicalising copy on the device ->]
+// asynchronous copy into one of two pinned buffers -> a handful of host threads move the chunk into the caller's
+// (pageable) memory while the next chunk is in flight.  canon: non-finite -> NaN on the way (Dataset.numpy,
+// src/python_bindings.rs:81-92 / masked_vector dataset.rs:64-72) -- on the device, not in a host loop.
+static int d2h_pipelined(ppca_ctx *ctx, double *dst, const double *src, size_t n, bool canon) {
+    constexpr size_t CHUNK = size_t(8) << 20;  // doubles: 64 MB
+    if (n == 0) return PPCA_OK;
+    if (n < (size_t(1) << 19)) {  // small: one plain copy
+        if (canon) {
+            BufRef tmp;
+            if (int rc = dev_alloc(sizeof(double) * n, &tmp)) return rc;
+            HIP_TRY(launch_canon_copy(src, static_cast<double *>(tmp->p), (int64_t)n, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(dst, tmp->p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            return PPCA_OK;
+        }
+        HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return PPCA_OK;
+    }
+    if (!ctx->pin[0]) {
+        for (int b = 0; b < 2; ++b) HIP_TRY(hipHostMalloc(&ctx->pin[b], CHUNK * sizeof(double), hipHostMallocDefault));
+        ctx->pin_cap = CHUNK * sizeof(double);
+    }
+    if (canon)
+        for (int b = 0; b < 2; ++b)
+            if (int rc = ensure(ctx->canon[b], ctx->canon_cap[b], CHUNK * sizeof(double))) return rc;
+    const size_t nch = (n + CHUNK - 1) / CHUNK;
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)std::min<unsigned>(8u, std::max<unsigned>(1u, hw / 2));
+    if (const char *e = getenv("PPCA_D2H_THREADS")) T = std::max(1, atoi(e));
+    std::atomic<long> ready{0};
+    std::atomic<bool> failed{false};
+    std::vector<std::atomic<int>> done(nch);
+    for (auto &x : done) x.store(0);
+    auto chunk_len = [&](size_t c) { return std::min(CHUNK, n - c * CHUNK); };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t)
+        pool.emplace_back([&, t] {
+            for (size_t c = 0; c < nch; ++c) {
+                while (ready.load(std::memory_order_acquire) <= (long)c) {
+                    if (failed.load()) return;
+                    std::this_thread::yield();
+                }
+                const size_t len = chunk_len(c), per = (len + T - 1) / T, a = std::min(len, per * t), b = std::min(len, a + per);
+                if (b > a) std::memcpy(dst + c * CHUNK + a, static_cast<const double *>(ctx->pin[c & 1]) + a, sizeof(double) * (b - a));
+                done[c].fetch_add(1, std::memory_order_release);
+            }
+        });
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipError_t err = hipSuccess;
+    auto issue = [&](size_t c) -> hipError_t {
+        const size_t len = chunk_len(c);
+        const double *from = src + c * CHUNK;
+        if (canon) {
+            double *stg = static_cast<double *>(ctx->canon[c & 1]->p);
+            if (hipError_t e = launch_canon_copy(from, stg, (int64_t)len, ctx->stream); e != hipSuccess) return e;
+            from = stg;
+        }
+        if (hipError_t e = hipMemcpyAsync(ctx->pin[c & 1], from, sizeof(double) * len, hipMemcpyDeviceToHost, ctx->stream); e != hipSuccess) return e;
+        return hipEventRecord(ev[c & 1], ctx->stream);
+    };
+    for (int b = 0; b < 2 && err == hipSuccess; ++b) err = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);
+    if (err == hipSuccess) err = issue(0);
+    for (size_t c = 0; c < nch && err == hipSuccess; ++c) {
+        if (c + 1 < nch) {
+            if (c >= 1)  // the other pinned buffer is free once every thread has emptied chunk c - 1
+                while (done[c - 1].load(std::memory_order_acquire) < T) std::this_thread::yield();
+            err = issue(c + 1);
+            if (err != hipSuccess) break;
+        }
+        err = hipEventSynchronize(ev[c & 1]);
+        if (err == hipSuccess) ready.store((long)c + 1, std::memory_order_release);
+    }
+    if (err != hipSuccess) failed.store(true);
+    for (auto &th : pool) th.join();
+    for (int b = 0; b < 2; ++b)
+        if (ev[b]) (void)hipEventDestroy(ev[b]);
+    if (err != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return fail(PPCA_ERR_HIP, "device-to-host copy failed: %s", hipGetErrorString(err));
+    }
+    return PPCA_OK;
+}
+
 // ------------------------------------------------------------------ misc
 extern "C" const char *ppca_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t ppca_abi_version(void) { return PPCA_ABI_VERSION; }
 extern "C" int32_t ppca_path_kind(int32_t d, int32_t k) {
-    if (d < 1 || k < 1) return PPCA_ERR_INVALID;
+    if (d < 1 || k < 0) return PPCA_ERR_INVALID;
+    if (k == 0) k = 1;  // state size 0 runs as one zero column (ppca_handles.hpp, ppca_model)
     if (d <= FUSED_MAX_D && k <= FUSED_MAX_K) return 1;
     if (k <= GENERIC_MAX_K) return 0;
     return PPCA_ERR_UNSUPPORTED;
@@ -496,13 +586,8 @@ extern "C" int ppca_dataset_to_host(ppca_dataset *ds, double *out) {
     if (!ds || (!out && ds->n > 0)) return fail(PPCA_ERR_INVALID, "null argument");
     if (ds->n == 0) return PPCA_OK;
     USE_CTX(ds->ctx);
-    HIP_TRY(hipStreamSynchronize(ds->ctx->stream));
-    HIP_TRY(hipMemcpy(out, ds->X, sizeof(double) * (size_t)ds->n * ds->d, hipMemcpyDeviceToHost));
     // masked_vector (dataset.rs:64-72): masked -> NaN; +-inf inputs are masked, so they come back NaN too
-    const size_t tot = (size_t)ds->n * ds->d;
-    for (size_t i = 0; i < tot; ++i)
-        if (!std::isfinite(out[i])) out[i] = NAN;
-    return PPCA_OK;
+    return d2h_pipelined(ds->ctx, out, ds->X, (size_t)ds->n * ds->d, true);
 }
 
 extern "C" int ppca_dataset_weights_to_host(ppca_dataset *ds, double *out) {
@@ -540,8 +625,11 @@ extern "C" int ppca_model_alloc(ppca_ctx *ctx, int32_t d, int32_t k, ppca_model 
     auto m = std::make_unique<ppca_model>();
     m->ctx = ctx;
     m->d = d;
-    m->k = k;
-    if (int rc = dev_alloc(sizeof(double) * (size_t)model_len(d, k), &m->buf)) return rc;
+    m->zero_state = k == 0;
+    m->k = k == 0 ? 1 : k;
+    if (int rc = dev_alloc(sizeof(double) * (size_t)model_len(d, m->k), &m->buf)) return rc;
+    if (m->zero_state)  // (the zero column; a finalisation into this model keeps it at zero: cross = 0)
+        HIP_TRY(hipMemsetAsync(m->buf->p, 0, sizeof(double) * (size_t)model_len(d, m->k), ctx->stream));
     *out = m.release();
     return PPCA_OK;
 }
@@ -551,13 +639,14 @@ extern "C" int ppca_model_create(ppca_ctx *ctx, int32_t d, int32_t k, double sig
     if (!mean || (k > 0 && !transform)) return fail(PPCA_ERR_INVALID, "null model arrays");
     ppca_model *m = nullptr;
     if (int rc = ppca_model_alloc(ctx, d, k, &m)) return rc;
-    std::vector<double> h((size_t)model_len(d, k));
+    const int ki = m->k;  // (k = 0: one zero column)
+    std::vector<double> h((size_t)model_len(d, ki), 0.0);
     h[0] = sigma;
     h[1] = sigma * sigma;  // isotropic_noise.powi(2), output_covariance.rs:62
     h[2] = std::log(sigma);
     h[3] = 0.0;
     if (k > 0) std::memcpy(h.data() + MODEL_HDR, transform, sizeof(double) * (size_t)d * k);
-    std::memcpy(h.data() + MODEL_HDR + (size_t)d * k, mean, sizeof(double) * d);
+    std::memcpy(h.data() + MODEL_HDR + (size_t)d * ki, mean, sizeof(double) * d);
     hipError_t e = hipMemcpyAsync(m->p(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -575,7 +664,7 @@ extern "C" int ppca_model_download(ppca_model *m, double *sigma, double *transfo
     HIP_TRY(hipMemcpyAsync(h.data(), m->p(), sizeof(double) * h.size(), hipMemcpyDeviceToHost, m->ctx->stream));
     HIP_TRY(hipStreamSynchronize(m->ctx->stream));
     if (sigma) *sigma = h[0];
-    if (transform && m->k > 0) std::memcpy(transform, h.data() + MODEL_HDR, sizeof(double) * (size_t)m->d * m->k);
+    if (transform && m->k_user() > 0) std::memcpy(transform, h.data() + MODEL_HDR, sizeof(double) * (size_t)m->d * m->k);
     if (mean) std::memcpy(mean, h.data() + MODEL_HDR + (size_t)m->d * m->k, sizeof(double) * m->d);
     return PPCA_OK;
 }
@@ -588,10 +677,10 @@ extern "C" int ppca_model_free(ppca_model *m) {
     return PPCA_OK;
 }
 extern "C" int32_t ppca_model_output_size(const ppca_model *m) { return m ? m->d : 0; }
-extern "C" int32_t ppca_model_state_size(const ppca_model *m) { return m ? m->k : 0; }
+extern "C" int32_t ppca_model_state_size(const ppca_model *m) { return m ? m->k_user() : 0; }
 
 // ------------------------------------------------------------------ EM step
-extern "C" int64_t ppca_stats_len(int32_t d, int32_t k) { return StatsLayout(d, k).len; }
+extern "C" int64_t ppca_stats_len(int32_t d, int32_t k) { return StatsLayout(d, k == 0 ? 1 : k).len; }  // (k = 0: one zero column)
 
 static int check_pair(const ppca_dataset *ds, const ppca_model *model) {
     if (!ds || !model) return fail(PPCA_ERR_INVALID, "null dataset or model");
@@ -760,6 +849,10 @@ extern "C" int ppca_em_finalize_host(int32_t d, int32_t k, double sigma, const d
                                      double *transform_out, double *mean_out) {
     if (d < 1 || k < 0 || !mean || !stats || !sigma_out || !mean_out || (k > 0 && (!transform || !transform_out)))
         return fail(PPCA_ERR_INVALID, "null argument");
+    if (k == 0) {  // state size 0 = one zero column (statistics of ppca_stats_len(d, 0) = ppca_stats_len(d, 1) doubles)
+        std::vector<double> c0((size_t)d, 0.0), c1((size_t)d, 0.0);
+        return ppca_em_finalize_host(d, 1, sigma, c0.data(), mean, stats, prior, sigma_out, c1.data(), mean_out);
+    }
     if (int rc = check_prior(prior)) return rc;
     (void)sigma;
     const StatsLayout L(d, k);
@@ -801,7 +894,8 @@ extern "C" int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const
                                 const ppca_prior *prior, ppca_model *out) {
     if (!ctx || !model_in || !stats_dev || !out) return fail(PPCA_ERR_INVALID, "null argument");
     if (out == model_in || out->buf == model_in->buf) return fail(PPCA_ERR_INVALID, "out may not alias model_in");
-    if (out->d != model_in->d || out->k != model_in->k) return fail(PPCA_ERR_INVALID, "model shapes differ");
+    if (out->d != model_in->d || out->k != model_in->k || out->zero_state != model_in->zero_state)
+        return fail(PPCA_ERR_INVALID, "model shapes differ");
     if (int rc = check_path(model_in->d, model_in->k)) return rc;
     if (int rc = check_prior(prior)) return rc;
     USE_CTX(ctx);
@@ -967,8 +1061,9 @@ extern "C" int ppca_llk(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model
 
 extern "C" int ppca_infer(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *states_host,
                           double *covs_host) {
-    if (!ctx || !states_host) return fail(PPCA_ERR_INVALID, "null argument");
+    if (!ctx || (!states_host && !(model && model->zero_state))) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_pair(ds, model)) return rc;
+    if (model->zero_state) return PPCA_OK;  // n x 0 states, n x 0 x 0 covariances: nothing to write
     USE_CTX(ctx);
     const int k = model->k;
     BufRef st, cv;
@@ -979,10 +1074,9 @@ extern "C" int ppca_infer(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *mod
                           nullptr, 0, nullptr))
         return rc;
     if (ds->n > 0) {
-        HIP_TRY(hipMemcpyAsync(states_host, st->p, sizeof(double) * (size_t)ds->n * k, hipMemcpyDeviceToHost, ctx->stream));
+        if (int rc = d2h_pipelined(ctx, states_host, static_cast<const double *>(st->p), (size_t)ds->n * k, false)) return rc;
         if (covs_host)
-            HIP_TRY(hipMemcpyAsync(covs_host, cv->p, sizeof(double) * (size_t)ds->n * k * k, hipMemcpyDeviceToHost,
-                                   ctx->stream));
+            if (int rc = d2h_pipelined(ctx, covs_host, static_cast<const double *>(cv->p), (size_t)ds->n * k * k, false)) return rc;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PPCA_OK;

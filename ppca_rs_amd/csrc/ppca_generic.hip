@@ -209,6 +209,136 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 
+// ------------------------------------------------------------------ the two skinny statistics products in ONE pass over X
+//     [U | totals] (d x (k+1)) += Mask^T . [wz | w]        (for total_deviation, ppca_model.rs:338-348)
+//     [cross | sumx] (d x (k+1)) += X~^T . [wz | w]        (:281-293)
+// gemm_kernel<2> / <3> compute them one after the other on 64-column tiles: at k + 1 <= 16 three quarters of every MFMA
+// are padding and X is read twice (1.8 + 2.0 ms of a 8 ms chunk at d = 256, k = 11).  Here a wave owns a strip of 64
+// dimensions x 16 NT columns of BOTH products; the A operands come straight from global memory (lane = dimension 16 r +
+// lane % 16 of sample 4 s + lane / 16: whole 128-byte segments of four rows, no LDS), one read of X feeds both
+// products, and the mask / centring is a compare and a select on the way.  Samples are cut into slices (grid.x), the
+// slice partials summed in slice order (deterministic).
+typedef double sd4_t __attribute__((ext_vector_type(4)));
+template <int NT>
+__global__ __launch_bounds__(256) void skinny_xt_kernel(const double *X, int64_t ldx, int64_t n, int d, const double *mean,
+                                                        const double *Bz, int ncols, int64_t rows_per_slice, double *part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int dbase = blockIdx.y * 256 + 64 * wave;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slice, r1 = r0 + rows_per_slice < n ? r0 + rows_per_slice : n;
+    sd4_t accM[4][NT], accX[4][NT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) accM[r][t] = accX[r][t] = sd4_t{0, 0, 0, 0};
+    // Every load is unconditional (clamped to a real element) and the validity applied by selects afterwards: a load
+    // inside a divergent branch gets its own exec-masked region and wait, and the loop turns latency-bound.
+    double mu[4];
+    bool dok[4];
+    int coff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = dbase + 16 * r + l15;
+        dok[r] = j < d;
+        coff[r] = dok[r] ? j : d - 1;
+        mu[r] = mean[coff[r]];
+    }
+    int boff[NT];
+    bool bok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = 16 * t + l15;
+        bok[t] = c < ncols;
+        boff[t] = bok[t] ? c : ncols - 1;
+    }
+    constexpr int UN = 4;  // k-steps (of four samples) whose operands are requested before the first of them is used
+    for (int64_t s0 = r0; s0 < r1; s0 += 4 * UN) {
+        double xv[UN][4], bv[UN][NT];
+        bool valid[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t row = s0 + 4 * u + l4;
+            valid[u] = row < r1;
+            const int64_t rc = valid[u] ? row : r1 - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[u][r] = X[rc * ldx + coff[r]];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[u][t] = Bz[rc * ncols + boff[t]];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            double am[4], xt[4], bz[NT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ob = valid[u] && dok[r] && __builtin_fabs(xv[u][r]) < __builtin_inf();
+                am[r] = ob ? 1.0 : 0.0;
+                xt[r] = ob ? xv[u][r] - mu[r] : 0.0;  // select, never multiply (utils.rs:118-127)
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bz[t] = (valid[u] && bok[t]) ? bv[u][t] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    accM[r][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[r], bz[t], accM[r][t], 0, 0, 0);
+                    accX[r][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[r], bz[t], accX[r][t], 0, 0, 0);
+                }
+        }
+    }
+    // part[slice][product][dim (padded to 256 per grid.y)][16 NT]; C/D map: row = l4 + 4 q, column = l15
+    const int dpad = gridDim.y * 256;
+    double *pm = part + ((int64_t)blockIdx.x * 2) * dpad * (16 * NT), *px = pm + (int64_t)dpad * (16 * NT);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t dim = dbase + 16 * r + l4 + 4 * q;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                pm[dim * (16 * NT) + 16 * t + l15] = accM[r][t][q];
+                px[dim * (16 * NT) + 16 * t + l15] = accX[r][t][q];
+            }
+        }
+}
+// stats += sum over the slices, in slice order: product 0 -> [U | totals], product 1 -> [cross | sumx]
+__global__ void skinny_xt_reduce_kernel(const double *part, int nslices, int dpad, int ncolpad, int d, int k, double *U, double *totals,
+                                        double *cross, double *sumx) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)dpad * ncolpad;
+    if (idx >= 2 * per) return;
+    const int prod = (int)(idx / per);
+    const int64_t rem = idx - prod * per;
+    const int dim = (int)(rem / ncolpad), c = (int)(rem - (int64_t)dim * ncolpad);
+    if (dim >= d || c > k) return;
+    double v = 0.0;
+    for (int sl = 0; sl < nslices; ++sl) v += part[((int64_t)sl * 2 + prod) * per + rem];
+    double *dst = prod == 0 ? (c < k ? U + (int64_t)dim * k + c : totals + dim) : (c < k ? cross + (int64_t)dim * k + c : sumx + dim);
+    *dst += v;
+}
+// returns false when the shape is not the skinny kernel's (k + 1 > 32 columns or not enough scratch): the caller falls
+// back on gemm_kernel<2> / <3>
+static bool launch_skinny_xt(const double *X, int64_t ldx, int64_t n, int d, int k, const double *mean, const double *Bz,
+                             double *stats, const StatsLayout &L, double *part_ws, int64_t part_cap, int n_cu, hipStream_t s,
+                             hipError_t *err) {
+    const int ncols = k + 1, nt = (ncols + 15) / 16;
+    if (nt > 2 || n < 1) return false;
+    const int gy = (d + 255) / 256, dpad = gy * 256, ncolpad = 16 * nt;
+    int64_t slices = std::max<int64_t>(1, (4 * (int64_t)n_cu) / gy);   // four workgroups per CU: the loads of one cover the MFMAs of another
+    slices = std::min<int64_t>(slices, (n + 255) / 256);
+    slices = std::min<int64_t>(slices, part_cap / (2 * (int64_t)dpad * ncolpad));
+    if (slices < 1) return false;
+    const int64_t rps = ((n + slices - 1) / slices + 3) / 4 * 4;
+    slices = (n + rps - 1) / rps;
+    dim3 grid((unsigned)slices, (unsigned)gy);
+    if (nt == 1) hipLaunchKernelGGL((skinny_xt_kernel<1>), grid, dim3(256), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws);
+    else hipLaunchKernelGGL((skinny_xt_kernel<2>), grid, dim3(256), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws);
+    const int64_t tot = 2 * (int64_t)dpad * ncolpad;
+    hipLaunchKernelGGL(skinny_xt_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, part_ws, (int)slices, dpad, ncolpad, d, k,
+                       stats + L.U, stats + L.totals, stats + L.cross, stats + L.sumx);
+    *err = hipGetLastError();
+    return true;
+}
+
 // ------------------------------------------------------------------ int8-sliced exact contractions
 // Both large contractions of the pass have one EXACT operand, the 0/1 mask:
 //     G[i][c] = sum_j m_ij Q[j][c]        (samples x k', over the d dims)
@@ -345,19 +475,36 @@ __global__ __launch_bounds__(256) void gen_colstat_kernel(const double *V, int64
 // -> scale[c] and the chunk's guard flag (flags[1], reset by gen_colstat_kernel); sums in block order (deterministic)
 __global__ __launch_bounds__(256) void gen_colscale_kernel(const double *part, int nblocks, int64_t n, int kp, double *scale,
                                                            int *flags) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= kp) return;
+    // one workgroup per column: thread t takes blocks t, t + 256, ..., then a fixed tree over the threads
+    // (deterministic; one THREAD per column walked a million-row chunk's 4096 block partials alone: 1 ms per chunk)
+    __shared__ double rmx[256], rsm[256];
+    const int c = blockIdx.x, t = threadIdx.x;
     double mx = 0.0, sm = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = t; b < nblocks; b += 256) {
         mx = fmax(mx, part[((int64_t)b * 2) * kp + c]);
         sm += part[((int64_t)b * 2 + 1) * kp + c];
     }
-    int e = 0;
-    if (mx > 0.0 && mx < 1.0e300) (void)frexp(mx, &e);
-    scale[c] = ldexp(1.0, e - (7 * GQS - 2));
-    // finite, and the maximum within 2^20 of the mean magnitude
-    if (!(sm < 1.0e300) || !(mx * (double)n <= 1048576.0 * sm)) atomicOr(&flags[1], 1);
+    rmx[t] = mx;
+    rsm[t] = sm;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            rmx[t] = fmax(rmx[t], rmx[t + o]);
+            rsm[t] += rsm[t + o];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        mx = rmx[0];
+        sm = rsm[0];
+        int e = 0;
+        if (mx > 0.0 && mx < 1.0e300) (void)frexp(mx, &e);
+        scale[c] = ldexp(1.0, e - (7 * GQS - 2));
+        // finite, and the maximum within 2^20 of the mean magnitude
+        if (!(sm < 1.0e300) || !(mx * (double)n <= 1048576.0 * sm)) atomicOr(&flags[1], 1);
+    }
 }
+
 // digits of V[n][kp] (row-major) -> planes BtW[s][c][npad] (samples contiguous): 64 samples x 64 columns per
 // workgroup, lane = column (rows read as whole 512-byte segments), wave w = samples 16 w .. 16 w + 15 -- the 16 digits
 // of one (slice, column) are 16 consecutive bytes of the output: one 16-byte store, no transposition
@@ -405,10 +552,13 @@ struct I8GemmArgs {
     int64_t ldo;
     int accumulate;
     const int *guard;  // run only if *guard == 0
-    // split-K in two (blockIdx.z): half 0 covers [0, ksplit) and goes to `out`, half 1 covers [ksplit, K) and goes to the
-    // dense M x N buffer `out2` (overwritten), which add_partial_kernel then adds to `out` -- a fixed order.  Used
-    // where the tile grid is a few workgroups more than the chip holds at once (S: 520 tiles on 512 slots).
+    // split-K (blockIdx.z = slice z of nsplit): slice z covers [z ksplit, (z + 1) ksplit); slice 0 goes to `out`, slice
+    // z >= 1 to the dense M x N buffer out2 + (z - 1) M N (overwritten), which add_partial_kernel then adds to `out`
+    // in slice order -- a fixed order.  Used where the tile grid is a few workgroups more than the chip holds at once
+    // (S at config 4: 520 tiles on 512 slots, two slices) and where it is far too small to fill it (S at d = 256,
+    // k = 11: 6 tiles -- one step outside the fused kernel the statistics contraction ran on 12 of 256 CUs).
     int64_t ksplit;    // 0 = no split
+    int nsplit;
     double *out2;
 };
 
@@ -436,8 +586,10 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
     //  side -- measured SLOWER, 106 vs 97 ms per iteration at N = 400 k, d = 1024, k = 64: plain 2-D order kept)
     const int64_t m0 = (int64_t)blockIdx.y * TM;
     const int64_t n0 = (int64_t)blockIdx.x * 32;
-    const bool second = g.ksplit > 0 && blockIdx.z == 1;
-    const int64_t kbeg = second ? g.ksplit : 0, kend = (g.ksplit > 0 && !second) ? g.ksplit : g.K;
+    const int zs = g.ksplit > 0 ? (int)blockIdx.z : 0;
+    const bool second = zs > 0;
+    const int64_t kbeg = (int64_t)zs * g.ksplit;
+    const int64_t kend = g.ksplit > 0 ? (kbeg + g.ksplit < g.K ? kbeg + g.ksplit : g.K) : g.K;
     // Wave tile 64 rows x 16 columns x GQS slices (waves as 2 x 2 over the 128 x 32 workgroup tile): 4 A fragments
     // + GQS B fragments read from LDS per 4 GQS MFMAs of a 64-byte K-step -- 0.375 reads per MFMA where a 32 x 32
     // wave tile needs 0.56 (measured: the same 266 ms per iteration at config 4 either way -- LDS reads are not what
@@ -580,7 +732,7 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
 #pragma unroll
                 for (int s = GQS - 2; s >= 0; --s) v = v * 128.0 + (double)acc[a][s][r];
                 if (second) {
-                    g.out2[row * g.N + col] = v * sc;
+                    g.out2[(int64_t)(zs - 1) * g.M * g.N + row * g.N + col] = v * sc;
                 } else {
                     double *dst = g.out + row * g.ldo + col;
                     *dst = g.accumulate ? *dst + v * sc : v * sc;
@@ -763,6 +915,91 @@ __global__ __launch_bounds__(128) void solve_kernel(SolveArgs a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ per-sample solve, one LANE per sample (k <= 16)
+// The blocked / broadcast solvers below give a whole wave to one sample: right at k = 64, a 70-fold waste at k = 11
+// (13 k cycles per sample and wave: 6.4 ms of a 16 ms chunk one step outside the fused kernel).  Up to k = 16 the
+// packed Cholesky factor (136 doubles) fits a lane's registers, so the fused kernel's per-sample code (Posterior<K>,
+// ppca_small.hpp) runs here as it does there: 64 samples per wave instruction.  Same I/O contract as solve_kernel.
+template <int K, bool EM>
+__device__ __forceinline__ void solve_lane_body(const SolveArgs &a) {
+    constexpr int KP = K * (K + 1) / 2;
+    const double s2 = a.model[1], lnsig = a.model[2];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        double *g = a.G + i * KP;
+        double *bz = a.Bz + i * (K + 1);
+        Posterior<K> post;
+        double pm;
+        int pe;
+        post.factor([&](int e) { return g[e]; }, s2, pm, pe);
+        double z[K], quad, zz;
+        post.solve([&](int c) { return bz[c]; }, z, quad, zz);
+        const double wgt = a.w ? a.w[i] : 1.0;
+        const double xx = a.xx[i];
+        const int m = (int)a.mc[i];
+        const double lk = sample_llk(xx, quad, Posterior<K>::logdet(pm, pe), s2, lnsig, m, K);
+        double tr = 0.0;
+        double *sc = a.sc + i * 4;
+        if constexpr (EM) {
+#pragma unroll
+            for (int c = 0; c < K; ++c)  // w P = w (z z^T + s2 M^-1), packed
+                tr += post.minv_column(c, [&](int r, int cc, double v) { g[tri(r, cc)] = wgt * (z[r] * z[cc] + s2 * v); });
+#pragma unroll
+            for (int c = 0; c < K; ++c) bz[c] = wgt * z[c];
+            bz[K] = wgt;
+            sc[0] = m > 0 ? wgt * s2 * ((double)K - s2 * tr) : 0.0;
+            sc[1] = m > 0 ? wgt * (xx - quad - s2 * zz) : 0.0;
+            sc[2] = wgt * lk;
+            sc[3] = m > 0 ? 1.0 : 0.0;
+        } else {
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                bz[c] = z[c];  // unweighted state for the reconstruction pass
+                if (a.states) a.states[i * K + c] = z[c];
+            }
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+                (void)post.minv_column(c, [&](int r, int cc, double v) {
+                    const double sv = s2 * v;
+                    g[tri(r, cc)] = sv;  // Sigma packed, for covariance diagonals
+                    if (a.covs) {
+                        a.covs[(i * K + r) * K + cc] = sv;
+                        a.covs[(i * K + cc) * K + r] = sv;
+                    }
+                });
+            sc[0] = 0.0;
+            sc[1] = 0.0;
+            sc[2] = wgt * lk;
+            sc[3] = 0.0;
+            if (a.llks) a.llks[i] = lk;
+        }
+    }
+}
+template <int K, bool EM>
+__global__ __launch_bounds__(256) void solve_lane_kernel(SolveArgs a) {
+    solve_lane_body<K, EM>(a);
+}
+// k >= 13: the packed factor alone is 182..272 registers -- one wave per SIMD with the whole 512-entry file (the
+// accumulation half takes what the 256 directly addressable registers cannot hold; without the attribute: 148 dwords of
+// scratch per lane at k = 16)
+template <int K, bool EM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void solve_lane_wide_kernel(SolveArgs a) {
+    solve_lane_body<K, EM>(a);
+}
+template <int K>
+static hipError_t launch_solve_lane(const SolveArgs &a, int n_cu, hipStream_t s) {
+    int64_t blocks = (a.n + 255) / 256;
+    if (blocks > 8 * (int64_t)n_cu) blocks = 8 * (int64_t)n_cu;
+    if (blocks < 1) blocks = 1;
+    if constexpr (K >= 13) {
+        if (a.em) hipLaunchKernelGGL((solve_lane_wide_kernel<K, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((solve_lane_wide_kernel<K, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    } else {
+        if (a.em) hipLaunchKernelGGL((solve_lane_kernel<K, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((solve_lane_kernel<K, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ register-resident per-sample solve
@@ -1368,6 +1605,21 @@ static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
         const char *e = getenv("PPCA_GENERIC_SOLVE");
         return (e && e[0] == 'b') ? 1 : 0;
     }();
+    static const bool lane_ok = [] {  // PPCA_GENERIC_LANE_SOLVE=0: the wave-per-sample forms at every k (A/B runs)
+        const char *e = getenv("PPCA_GENERIC_LANE_SOLVE");
+        return !(e && atoi(e) == 0);
+    }();
+    if (lane_ok && a.k <= 16) {
+        switch (a.k) {
+#define PPCA_LANE_CASE(KK) \
+    case KK:               \
+        return launch_solve_lane<KK>(a, n_cu, s);
+            PPCA_LANE_CASE(1) PPCA_LANE_CASE(2) PPCA_LANE_CASE(3) PPCA_LANE_CASE(4) PPCA_LANE_CASE(5) PPCA_LANE_CASE(6)
+            PPCA_LANE_CASE(7) PPCA_LANE_CASE(8) PPCA_LANE_CASE(9) PPCA_LANE_CASE(10) PPCA_LANE_CASE(11) PPCA_LANE_CASE(12)
+            PPCA_LANE_CASE(13) PPCA_LANE_CASE(14) PPCA_LANE_CASE(15) PPCA_LANE_CASE(16)
+#undef PPCA_LANE_CASE
+        }
+    }
     if (!reg && form == 0) {
         if (a.k <= 16) return launch_solve_mfma<1>(a, grid, s);
         if (a.k <= 32) return launch_solve_mfma<2>(a, grid, s);
@@ -1386,17 +1638,36 @@ static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
 }
 
 // strided column sum of sc[n][4] (+ sum of weights) into scal[8]; one block, deterministic
-__global__ void scal_reduce_kernel(const double *sc, const double *w, int64_t n, double *scal, int accumulate) {
+// Two stages, both in a fixed order (deterministic): blocks of SCAL_ROWS samples -> part[block][5], then one workgroup
+// over the partials.  (One workgroup over a whole chunk -- a million rows at small k -- took milliseconds per chunk.)
+constexpr int SCAL_ROWS = 4096;
+__global__ __launch_bounds__(256) void scal_reduce_kernel(const double *sc, const double *w, int64_t n, double *part) {
     __shared__ double red[256][5];
     const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SCAL_ROWS, i1 = i0 + SCAL_ROWS < n ? i0 + SCAL_ROWS : n;
     double v[5] = {0, 0, 0, 0, 0};
-    for (int64_t i = tid; i < n; i += 256) {
+    for (int64_t i = i0 + tid; i < i1; i += 256) {
         v[0] += sc[i * 4 + 0];
         v[1] += sc[i * 4 + 1];
         v[2] += sc[i * 4 + 2];
         v[3] += sc[i * 4 + 3];
         v[4] += w ? w[i] : 1.0;
     }
+    for (int c = 0; c < 5; ++c) red[tid][c] = v[c];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o)
+            for (int c = 0; c < 5; ++c) red[tid][c] += red[tid + o][c];
+        __syncthreads();
+    }
+    if (tid < 5) part[(int64_t)blockIdx.x * 5 + tid] = red[0][tid];
+}
+__global__ __launch_bounds__(256) void scal_final_kernel(const double *part, int nblocks, double *scal, int accumulate) {
+    __shared__ double red[256][5];
+    const int tid = threadIdx.x;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int b = tid; b < nblocks; b += 256)
+        for (int c = 0; c < 5; ++c) v[c] += part[(int64_t)b * 5 + c];
     for (int c = 0; c < 5; ++c) red[tid][c] = v[c];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -1517,7 +1788,9 @@ static int64_t gen_chunk(int k) {
 // split-K scratch: up to 4 dense (d x k') partials (and >= 16 of the (d x (k+1)) ones)
 static int64_t gen_part_doubles(int d, int k) {
     const int64_t kp = (int64_t)k * (k + 1) / 2;
-    return std::max<int64_t>(4 * (int64_t)d * kp, 64 * (int64_t)d * (k + 1));
+    // (small shapes: room for up to 64 K-slices of the mask-side statistics contraction, capped at 64 MB)
+    return std::max<int64_t>(std::max<int64_t>(4 * (int64_t)d * kp, 64 * (int64_t)d * (k + 1)),
+                             std::min<int64_t>(64 * (int64_t)d * kp, (int64_t)8 << 20));
 }
 
 static int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
@@ -1528,7 +1801,7 @@ struct GenWs {
     // int8-sliced contractions
     unsigned char *A, *AT;
     signed char *BtQ, *BtW;
-    double *scaleQ, *scaleW, *colpart, *rmin;
+    double *scaleQ, *scaleW, *colpart, *rmin, *spart;
     int *flags;
     int dpad;
     int64_t npad;
@@ -1561,6 +1834,7 @@ static size_t carve_impl(void *ws, int d, int k, int64_t n, GenWs *out) {
     w.scaleW = static_cast<double *>(take(sizeof(double) * (size_t)kp));
     w.colpart = static_cast<double *>(take(sizeof(double) * 2 * (size_t)kp * (size_t)((w.chunk + 255) / 256)));
     w.rmin = static_cast<double *>(take(256));
+    w.spart = static_cast<double *>(take(sizeof(double) * 5 * (size_t)((w.chunk + SCAL_ROWS - 1) / SCAL_ROWS)));
     w.flags = static_cast<int *>(take(256));
     if (out) *out = w;
     return off;
@@ -1586,13 +1860,15 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int nslices) {
 
 // part_ws / part_cap: split-K scratch (doubles); a product whose tile grid would not fill the chip ~4x over
 // is cut along K into enough slices to do so.
-// out[r][c] += part[r][c] (the second K-half of a split int8 contraction)
-__global__ void add_partial_kernel(double *out, int64_t ldo, const double *part, int64_t M, int64_t N, const int *guard) {
+// out[r][c] += part[0][r][c] + part[1][r][c] + ... (the further K-slices of a split int8 contraction, in slice order)
+__global__ void add_partial_kernel(double *out, int64_t ldo, const double *part, int64_t M, int64_t N, int nparts, const int *guard) {
     if (guard && *guard != 0) return;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * N) return;
     const int64_t r = idx / N, c = idx - r * N;
-    out[r * ldo + c] += part[idx];
+    double v = out[r * ldo + c];
+    for (int z = 0; z < nparts; ++z) v += part[(int64_t)z * M * N + idx];
+    out[r * ldo + c] = v;
 }
 
 template <int TM, bool BUF>
@@ -1630,16 +1906,25 @@ static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
         dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 255) / 256), 1u);
         e = buf ? launch_i8gemm_t<256, true>(g, grid, s) : launch_i8gemm_t<256, false>(g, grid, s);
     } else {
-        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128), g.ksplit > 0 ? 2u : 1u);
+        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128), g.ksplit > 0 ? (unsigned)g.nsplit : 1u);
         e = buf ? launch_i8gemm_t<128, true>(g, grid, s) : launch_i8gemm_t<128, false>(g, grid, s);
     }
     if (e != hipSuccess) return e;
     if (g.ksplit > 0) {
         const int64_t tot = g.M * g.N;
         hipLaunchKernelGGL(add_partial_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, g.out, g.ldo, g.out2, g.M, g.N,
-                           g.guard);
+                           g.nsplit - 1, g.guard);
     }
     return hipGetLastError();
+}
+
+// PPCA_GENERIC_SKINNY=0: the two skinny statistics products through gemm_kernel<2> / <3> at every k (A/B runs)
+static bool skinny_ok() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_GENERIC_SKINNY");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
 }
 
 // PPCA_GENERIC_FP64=1: both large contractions on the fp64 MFMA always (A/B runs)
@@ -1774,16 +2059,20 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
             GTRY(launch_solve(a, n_cu, s));
         }
         double *scal = em ? stats + L.scalars : scal8;
-        hipLaunchKernelGGL(scal_reduce_kernel, dim3(1), dim3(256), 0, s, W.sc, wc, nc, scal, (em || r0 > 0) ? 1 : 0);
-        GTRY(hipGetLastError());
+        {
+            const int sb = (int)((nc + SCAL_ROWS - 1) / SCAL_ROWS);
+            hipLaunchKernelGGL(scal_reduce_kernel, dim3((unsigned)sb), dim3(256), 0, s, W.sc, wc, nc, W.spart);
+            hipLaunchKernelGGL(scal_final_kernel, dim3(1), dim3(256), 0, s, W.spart, sb, scal, (em || r0 > 0) ? 1 : 0);
+            GTRY(hipGetLastError());
+        }
         if (em) {
             if (i8) {
                 // column scales of wP over the chunk + its guard (flags[1]), digit planes, S += Mask^T . wP on the int8 MFMA
                 const int nb = (int)((nc + 255) / 256);
                 hipLaunchKernelGGL(gen_colstat_kernel, dim3((unsigned)((kp + 255) / 256), (unsigned)nb), dim3(256), 0, s, W.G,
                                    nc, (int)kp, W.colpart, W.flags);
-                hipLaunchKernelGGL(gen_colscale_kernel, dim3((unsigned)((kp + 255) / 256)), dim3(256), 0, s, W.colpart, nb, nc,
-                                   (int)kp, W.scaleW, W.flags);
+                hipLaunchKernelGGL(gen_colscale_kernel, dim3((unsigned)kp), dim3(256), 0, s, W.colpart, nb, nc, (int)kp, W.scaleW,
+                                   W.flags);
                 dim3 dg((unsigned)((kp + 63) / 64), (unsigned)(ncpad / 64));
                 hipLaunchKernelGGL(gen_wdigits_kernel, dg, dim3(256), 0, s, W.G, nc, (int)kp, W.npad, W.scaleW, W.BtW, W.flags);
                 GTRY(hipGetLastError());
@@ -1795,7 +2084,19 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
                     const int64_t tiles = ((q.M + 127) / 128) * ((q.N + 31) / 32), slots = 2 * (int64_t)n_cu;
                     if (tiles > slots && tiles < slots + slots / 2 && q.M * q.N <= W.part_cap && ncpad >= 256) {
                         q.ksplit = (ncpad / 2 + 63) / 64 * 64;
+                        q.nsplit = 2;
                         q.out2 = W.part;
+                    } else if (tiles < slots) {
+                        // ... and a grid far below it leaves the chip idle: cut the samples into enough slices to fill it
+                        int64_t ns = (slots + tiles - 1) / tiles;
+                        ns = std::min<int64_t>(ns, ncpad / 4096);                                   // >= 4096 samples per slice
+                        ns = std::min<int64_t>(ns, W.part_cap / std::max<int64_t>(1, q.M * q.N) + 1);  // partials that fit
+                        if (ns > 64) ns = 64;
+                        if (ns >= 2) {
+                            q.ksplit = ((ncpad + ns - 1) / ns + 63) / 64 * 64;
+                            q.nsplit = (int)((ncpad + q.ksplit - 1) / q.ksplit);
+                            q.out2 = W.part;
+                        }
                     }
                 }
                 GTRY(launch_i8gemm(q, s));
@@ -1806,13 +2107,18 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
             g.guard = i8 ? W.flags + 1 : nullptr; g.run_if = 1;
             GTRY(launch_gemm<2>(g, s, n_cu, W.part, W.part_cap));
             g.guard = nullptr;
-            // [U | totals] += Mask^T . [wz | w]
-            g.B = W.Bz; g.ldb = k + 1; g.N = k + 1;
-            g.out0 = stats + L.U; g.ld0 = k; g.ncols0 = k; g.out1 = stats + L.totals; g.ld1 = 1;
-            GTRY(launch_gemm<2>(g, s, n_cu, W.part, W.part_cap));
-            // [cross | sumx] += X~^T . [wz | w]
-            g.out0 = stats + L.cross; g.out1 = stats + L.sumx;
-            GTRY(launch_gemm<3>(g, s, n_cu, W.part, W.part_cap));
+            hipError_t serr = hipSuccess;
+            if (skinny_ok() && launch_skinny_xt(Xc, ldx, nc, d, k, mean, W.Bz, stats, L, W.part, W.part_cap, n_cu, s, &serr)) {
+                GTRY(serr);  // both skinny products in one pass over the chunk's rows (k + 1 <= 32 columns)
+            } else {
+                // [U | totals] += Mask^T . [wz | w]
+                g.B = W.Bz; g.ldb = k + 1; g.N = k + 1;
+                g.out0 = stats + L.U; g.ld0 = k; g.ncols0 = k; g.out1 = stats + L.totals; g.ld1 = 1;
+                GTRY(launch_gemm<2>(g, s, n_cu, W.part, W.part_cap));
+                // [cross | sumx] += X~^T . [wz | w]
+                g.out0 = stats + L.cross; g.out1 = stats + L.sumx;
+                GTRY(launch_gemm<3>(g, s, n_cu, W.part, W.part_cap));
+            }
         } else if (recon) {
             const int64_t tot = nc * d;
             hipLaunchKernelGGL(recon_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, ldx, nc, d, k,

@@ -99,7 +99,13 @@ struct ppca_dataset {
 
 struct ppca_model {
     ppca_ctx *ctx = nullptr;
-    int d = 0, k = 0;
+    int d = 0, k = 0;  // k: the state size the kernels run with
+    // State size 0 (an isotropic Gaussian around the mean; the reference accepts it, ppca_model.rs:51-70, :399-402) is
+    // carried as ONE zero transform column: with c_j = 0 every pass reproduces the k = 0 model exactly (G = 0, M = sigma^2,
+    // z = 0, Sigma = 1; ln det M + 2 ln(sigma)(m - 1) = 2 m ln(sigma); cross = 0 keeps the column at zero; the trace
+    // term sigma^2 (k - sigma^2 tr M^-1) vanishes).  zero_state marks such a model: the caller sees state size 0.
+    bool zero_state = false;
+    int k_user() const { return zero_state ? 0 : k; }
     BufRef buf;
     double *p() const { return static_cast<double *>(buf->p); }
 };

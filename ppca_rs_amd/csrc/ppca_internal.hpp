@@ -75,6 +75,8 @@ hipError_t launch_synth(const double *c_dev, const double *mean_dev, double *z_w
                         uint64_t seed, hipStream_t s);
 hipError_t launch_column_presence(const double *X, int64_t ldx, int64_t n, int d, int *present, hipStream_t s);
 hipError_t launch_fill(double *p, int64_t n, double v, hipStream_t s);
+// dst[i] = finite(src[i]) ? src[i] : NaN (src, dst 16-byte aligned)
+hipError_t launch_canon_copy(const double *src, double *dst, int64_t n, hipStream_t s);
 // debug: C/D layout probe of v_mfma_f64_16x16x4_f64 (out: 16 x 16 row-major)
 hipError_t launch_mfma_i8_probe(const int *a, const int *b, int *out, hipStream_t s);
 hipError_t launch_mfma_probe(const double *a16x4, const double *b4x16, double *out16x16, hipStream_t s);

@@ -1429,6 +1429,27 @@ __global__ void column_presence_kernel(const double *X, int64_t ldx, int64_t n, 
     if (any) atomicOr(&present[j], 1);
 }
 
+// dst[i] = src[i] if finite, NaN otherwise: masked entries leave the device in the canonical form of masked_vector
+// (dataset.rs:64-72; +-inf inputs are masked, so they come back NaN too)
+__global__ void canon_copy_kernel(const double *src, double *dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        d2_t v = *reinterpret_cast<const d2_t *>(src + i);
+        v[0] = __builtin_isfinite(v[0]) ? v[0] : __builtin_nan("");
+        v[1] = __builtin_isfinite(v[1]) ? v[1] : __builtin_nan("");
+        *reinterpret_cast<d2_t *>(dst + i) = v;
+    } else if (i < n) {
+        dst[i] = __builtin_isfinite(src[i]) ? src[i] : __builtin_nan("");
+    }
+}
+hipError_t launch_canon_copy(const double *src, double *dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int64_t pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(canon_copy_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+
 __global__ void fill_kernel(double *p, int64_t n, double v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

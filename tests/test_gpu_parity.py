@@ -982,3 +982,87 @@ def test_block_cache_reuses_and_trims(P):
     assert released >= n * d * 8, released
     assert ctx.trim() == 0
     np.testing.assert_array_equal(model.smooth(ds).numpy(), want)
+
+
+@pytest.mark.gpu
+def test_state_size_zero_is_the_isotropic_model(P):
+    """state_size = 0 (ppca_model.rs:51-70 with an empty transform, to_canonical :399-402): an isotropic Gaussian around
+    the mean.  Checked against the closed forms: llk_i = -1/2 [|x~_i|^2 / s^2 + 2 m_i ln s + m_i ln 2 pi]; smooth = mean;
+    extrapolate keeps the observed values; iterate moves only the mean and sigma:
+    mean_j += sum_i w_i m_ij x~_ij / sum_i w_i m_ij,  sigma^2 = sum_i w_i |x~_i|^2 / sum_ij w_i m_ij  (:328-377 with no
+    transform: the trace term and C z vanish; the noise sums use the OLD mean)."""
+    rng = np.random.default_rng(11)
+    n, d = 700, 40
+    x = 0.7 * rng.standard_normal((n, d)) + rng.standard_normal(d)
+    x[rng.random((n, d)) < 0.3] = np.nan
+    x[5] = np.nan  # an all-masked sample
+    w = rng.uniform(0.5, 2.0, n)
+    mu, s = rng.standard_normal(d), 0.8
+    m = P.PPCAModel(s, np.zeros((d, 0)), mu)
+    assert m.state_size == 0 and m.n_parameters == 1 + d and m.to_canonical() is m
+    ds = P.Dataset(x, w)
+    ob = np.isfinite(x)
+    xt = np.where(ob, x - mu, 0.0)
+    mi = ob.sum(axis=1)
+    llks = -0.5 * ((xt ** 2).sum(axis=1) / s ** 2 + 2 * mi * np.log(s) + mi * np.log(2 * np.pi))
+    llks[mi == 0] = 0.0
+    assert _rel(m.llks(ds), llks) < 1e-12
+    assert abs(m.llk(ds) - (w * llks).sum()) < 1e-10 * abs((w * llks).sum())
+    np.testing.assert_allclose(m.smooth(ds).numpy(), np.tile(mu, (n, 1)), rtol=0, atol=1e-15)
+    ex = m.extrapolate(ds).numpy()
+    np.testing.assert_array_equal(ex[ob], x[ob])
+    np.testing.assert_allclose(ex[~ob], np.tile(mu, (n, 1))[~ob], rtol=0, atol=1e-15)
+    inf = m.infer(ds)
+    assert inf.states().shape == (n, 0) and len(inf.covariances()) == n
+    new, llk = m.iterate_with_llk(ds)
+    assert new.state_size == 0 and new.transform.shape == (d, 0)
+    tot = (w[:, None] * ob).sum(axis=0)
+    mean_want = mu + (w[:, None] * xt).sum(axis=0) / tot
+    s_want = np.sqrt((w * (xt ** 2).sum(axis=1)).sum() / tot.sum())
+    assert _rel(new.mean, mean_want) < 1e-12 and abs(new.isotropic_noise - s_want) < 1e-12 * s_want
+    assert abs(llk - (w * llks).sum()) < 1e-10 * abs(llk)
+    # PPCAModel.init accepts it, the trainer runs on it and the likelihood does not decrease
+    m0 = P.PPCAModel.init(0, ds, seed=1)
+    assert m0.state_size == 0
+    m1 = m0.iterate(ds)
+    assert m1.llk(ds) >= m0.llk(ds)
+    # a mixture may hold such a component next to ordinary ones (state sizes differ per component, mix.rs:50-71)
+    mix = P.PPCAMix([m, P.PPCAModel(0.5, rng.standard_normal((d, 2)), mu + 1.0)], np.zeros(2))
+    mix1, mllk = mix.iterate_with_llk(ds)
+    assert mix1.state_sizes == [0, 2] and np.isfinite(mllk) and mix1.llk(ds) >= mllk - 1e-9 * abs(mllk)
+
+
+@pytest.mark.gpu
+def test_filter_extrapolate_is_smooth(P):
+    """The README's name for the smoothing pass (readme.md:62; the binding calls it `smooth`, src/python_bindings.rs:488-490)."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((300, 24))
+    x[rng.random(x.shape) < 0.3] = np.nan
+    m = P.PPCAModel(0.4, rng.standard_normal((24, 3)), rng.standard_normal(24))
+    ds = P.Dataset(x)
+    np.testing.assert_array_equal(m.filter_extrapolate(ds).numpy(), m.smooth(ds).numpy())
+    mix = P.PPCAMix([m, P.PPCAModel(0.6, rng.standard_normal((24, 3)), rng.standard_normal(24))], np.log([0.4, 0.6]))
+    np.testing.assert_array_equal(mix.filter_extrapolate(ds).numpy(), mix.smooth(ds).numpy())
+
+
+@pytest.mark.gpu
+def test_large_downloads_are_pipelined_and_canonical(P):
+    """Dataset.numpy() / infer() of blocks larger than one 64 MB chunk leave through the pipelined copy (canonicalising
+    kernel -> pinned chunk buffers -> host threads): masked and +-inf entries come back NaN (dataset.rs:64-72), everything
+    else bit for bit; the covariances of a large infer() equal those of its slices."""
+    rng = np.random.default_rng(13)
+    n, d = 700_000, 32  # 179 MB: three chunks
+    x = rng.standard_normal((n, d))
+    x[rng.random((n, d)) < 0.2] = np.nan
+    x[::1001, 3] = np.inf
+    x[::997, 5] = -np.inf
+    ds = P.Dataset(x)
+    back = ds.numpy()
+    want = np.where(np.isfinite(x), x, np.nan)
+    assert np.array_equal(np.isnan(back), np.isnan(want))
+    np.testing.assert_array_equal(back[np.isfinite(want)], want[np.isfinite(want)])
+    m = P.PPCAModel(0.5, rng.standard_normal((d, 4)), rng.standard_normal(d))
+    inf = m.infer(ds)  # covariances: 700 000 x 16 doubles = 90 MB
+    part = m.infer(ds._slice(650_000, 1000))
+    np.testing.assert_array_equal(inf.states()[650_000:651_000], part.states())
+    np.testing.assert_array_equal(np.array(inf.covariances()[650_000:651_000]), np.array(part.covariances()))
