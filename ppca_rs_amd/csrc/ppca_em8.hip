@@ -86,7 +86,9 @@ struct Cfg8 {
     static constexpr int OFF_P1 = OFF_P0 + PLANE_BYTES / 8;  // ... and of its second
     static constexpr int OFF_E = OFF_P1 + PLANE_BYTES / 8;  // column exponents (NCOL ints), flags
     static constexpr int OFF_BAR = OFF_E + NCOL / 2 + 4;  // counters: front barrier, back barrier, tiles digitised, violation stamp
-    static constexpr int LDS_DOUBLES = OFF_BAR + 4;  // (8 counters)
+    static constexpr int OFF_MU = OFF_BAR + 4;            // the mean (DP doubles, zero past d): re-read by the staging of every tile
+    static constexpr int OFF_K = OFF_MU + DP;             // model scalars: sigma^2, 1 / sigma^2, ln sigma (re-read per tile)
+    static constexpr int LDS_DOUBLES = OFF_K + 4;
     static_assert(NCOL / 2 <= 64, "one back wave digitises NCOL / 2 (column, chunk) items");
     static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget");
 };
@@ -119,7 +121,10 @@ __device__ __forceinline__ void wait_counter(const unsigned *ctr, unsigned need)
 #define E8_STAMP(i)
 #endif
 
-template <int K, bool GATHER>
+// WEIGHTED: the dataset carries sample weights (PassArgs::w).  A template parameter because the weighted pass takes a
+// logarithm per sample and tile (the unweighted one multiplies the determinants up and takes one per lane per kernel):
+// the constants of that logarithm were what the register allocator spilled in the un-weighted hot kernel.
+template <int K, bool GATHER, bool WEIGHTED>
 __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     using cfg = Cfg8<K>;
     constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS, BS = cfg::BS,
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     const int64_t n = p.n_dev ? (int64_t)*p.n_dev : p.n;
     const double *mC = p.model + MODEL_HDR;
     const double *mMean = mC + (int64_t)d * K;
-    const double s2 = p.model[1], lnsig = p.model[2];
+    const double s2_k = p.model[1], lnsig_k = p.model[2];
 
     for (int idx = tid; idx < cfg::DP * CS; idx += 512) {
         int j = idx / CS, a = idx - j * CS;
@@ -174,7 +179,13 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     static_assert(L_DEV + 6 * B <= 14 * B, "scalar slots");
     for (int idx = tid; idx < L_DEV + 6 * B; idx += 512) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
     for (int idx = tid; idx < cfg::DP * 4; idx += 512) Mb[idx] = 0u;
+    for (int idx = tid; idx < cfg::DP; idx += 512) sm[cfg::OFF_MU + idx] = idx < d ? mMean[idx] : 0.0;
     if (tid < 8) ctr[tid] = 0u;
+    if (tid == 0) {
+        sm[cfg::OFF_K] = s2_k;
+        sm[cfg::OFF_K + 1] = 1.0 / s2_k;
+        sm[cfg::OFF_K + 2] = lnsig_k;
+    }
 
     const int64_t ntiles = (n + B - 1) / B;
     const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -441,21 +452,11 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     // =============================================================== front role
     if (E8_FRONT_PRIO) __builtin_amdgcn_s_setprio(E8_FRONT_PRIO);
     unsigned fbar_target = 0u;
-    double mu[4];  // staging lane map: lane l holds dims 128 h + 2 l + e (element q = 2 h + e) of a row
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int j = 128 * (q >> 1) + 2 * lane_entry + (q & 1);
-        mu[q] = (j < d) ? mMean[j] : 0.0;
-    }
     d4_t accX[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) accX[r] = d4_t{0, 0, 0, 0};
-    const double inv_s2 = 1.0 / s2;
+    const double inv_s2_k = 1.0 / s2_k;
     double xr[RPW][4];
-    // observed <=> |x| < lim: +inf for a real dimension (finite test, dataset.rs:19-22), -1 for the padding past d
-    double lim[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) lim[q] = (128 * (q >> 1) + 2 * lane_entry + (q & 1) < d) ? __builtin_inf() : -1.0;
     const int64_t nleft = n - tile_begin * B;
     const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));  // rows from the workgroup's first row to the end
     const double *Xwg = p.X + tile_begin * B * p.ldx;
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     // bit l <-> dim 128 h + 2 l + e; qprep orders the digit table to match); each lane also shifts its own bit of every
     // ballot into st_mb (v_addc with the ballot as carry-in): after the wave's eight rows, byte = this dimension over
     // those samples (row r at bit 7 - r) -- the A operand of the back role's contraction.
+    double mu[4], lim[4];  // (rebuilt per tile in stage_tile)
     int st_wlo = 0, st_whi = 0;
     int st_mb[4] = {0, 0, 0, 0};
     double xx_run = 0.0;  // sum_i w_i |x~_i|^2 of this wave's rows (sigma^2 and the llk are linear in it)
@@ -541,10 +543,22 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
         });
         // wave-uniform: a real row of one of THIS workgroup's tiles
         const bool mine = (int)(t - tile_begin) * B + ri < nmine;
-        const double wr = mine ? (p.w ? p.w[t * B + ri] : 1.0) : 0.0;  // (scalar load)
+        const double wr = mine ? (WEIGHTED ? p.w[t * B + ri] : 1.0) : 0.0;  // (scalar load)
         xx_run += wr * pc_xx;
     };
+    // staging lane map: lane l holds dims 128 h + 2 l + e (element q = 2 h + e) of a row.  The lane's four means and
+    // limits (observed <=> |x| < lim: +inf for a real dimension -- the finite test of dataset.rs:19-22 --, -1 for the
+    // padding past d) are rebuilt per tile from the LDS copy of the mean: as loop invariants they sat in 16 registers
+    // across the solver and were what the register allocator spilled.
     auto stage_tile = [&](int64_t t, int lane) {
+        {
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            const d2_t m0 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 2 * lane);
+            const d2_t m1 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 + 2 * lane);
+            mu[0] = m0[0]; mu[1] = m0[1]; mu[2] = m1[0]; mu[3] = m1[1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lim[q] = (128 * (q >> 1) + 2 * lane + (q & 1) < d) ? __builtin_inf() : -1.0;
+        }
         const int rel = (int)(t - tile_begin);
         st_wlo = st_whi = 0;
         st_mb[0] = st_mb[1] = st_mb[2] = st_mb[3] = 0;
@@ -683,16 +697,18 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
         // wave 0 also owns z, llk and the scalars.  (The rows of W are free: the back role has cut the previous
         // tile's -- the counter above.)
         if (PAIRS || lane < B) {
+            // (the model scalars come back from LDS per tile: as loop invariants they -- and what hipcc derives from them --
+            //  were parked in spilled vector registers across the whole tile loop)
+            const double s2 = sm[cfg::OFF_K], inv_s2 = sm[cfg::OFF_K + 1], lnsig = sm[cfg::OFF_K + 2];
             const int i = lane & (B - 1);
             const int hi = PAIRS ? lane >> 5 : 0;
             const int64_t row = tile * B + i;
             const double *g0 = Gs + i * GS;
             const double *b1 = B1 + i * BS;
-            const double wgt = (row < n) ? (p.w ? p.w[row] : 1.0) : 0.0;
+            const double wgt = (row < n) ? (WEIGHTED ? p.w[row] : 1.0) : 0.0;
             const int m = __popcll(Msc[i * 4]) + __popcll(Msc[i * 4 + 1]) + __popcll(Msc[i * 4 + 2]) + __popcll(Msc[i * 4 + 3]);
             double *wrow = Ws + i * WS;
             double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;
-            const double sq_run = scl[wave * SQW + (PAIRS ? lane : i)];
             Posterior<K> post;
             double pm;
             int pe;
@@ -738,7 +754,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                     sc_ne += (row < n) ? 1.0 : 0.0;
                 }
                 const double lk0 = sample_llk_nolog(0.0, quad, inv_s2, lnsig, m, K);
-                if (p.w) {
+                if constexpr (WEIGHTED) {
                     if (!p.no_llk) sc_llk += wgt * (m > 0 ? lk0 - 0.5 * Posterior<K>::logdet(pm, pe) : 0.0);
                 } else {
                     const bool use = m > 0 && row < n;  // wgt is 1 for real rows
@@ -753,7 +769,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 scl[L_W + i] = run_w + sc_w;
                 scl[L_NE + i] = run_ne + sc_ne;
             }
-            scl[wave * SQW + (PAIRS ? lane : i)] = sq_run + sc_sq;
+            scl[wave * SQW + (PAIRS ? lane : i)] += sc_sq;  // (read here, not at the top: the value would sit in a spilled register across the solve)
         }
         E8_STAMP(2)
         __syncthreads();  // the tile's W rows are final: the back role starts on them
@@ -813,14 +829,14 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             for (int w = 0; w < NF; ++w) xx_tot += xxs[NF + w];
             const int li = lane < B ? lane : 0;
             double sc_llk = scl[L_LLK + li];
-            sc_llk -= 0.5 * (log(scl[L_PM + li]) + scl[L_PX + li] * LN_2);
+            if constexpr (!WEIGHTED) sc_llk -= 0.5 * (log(scl[L_PM + li]) + scl[L_PX + li] * LN_2);
             const double v1 = wave_sum(lane < B ? scl[L_DEV + li] : 0.0), v2 = wave_sum(lane < B ? sc_llk : 0.0),
                          v3 = wave_sum(lane < B ? scl[L_W + li] : 0.0), v4 = wave_sum(lane < B ? scl[L_NE + li] : 0.0);
             if (lane == 0) {
                 double *sc = out + L.scalars;
                 sc[SC_SQERR] = v0;
                 sc[SC_DEVSQ] = v1 + xx_tot;
-                sc[SC_LLK] = v2 - 0.5 * inv_s2 * xx_tot;
+                sc[SC_LLK] = v2 - 0.5 * inv_s2_k * xx_tot;
                 sc[SC_SUMW] = v3;
                 sc[SC_NONEMPTY] = v4;
                 sc[5] = 0.0;
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
 }
 
 // ------------------------------------------------------------------ launcher
-template <int K, bool GATHER>
+template <int K, bool GATHER, bool WEIGHTED>
 static hipError_t launch_em8_t(int grid, const PassArgs &a, hipStream_t s) {
     const size_t lds = sizeof(double) * Cfg8<K>::LDS_DOUBLES;
     static std::atomic<unsigned long long> done{0ull};
@@ -849,12 +865,12 @@ static hipError_t launch_em8_t(int grid, const PassArgs &a, hipStream_t s) {
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&em8_kernel<K, GATHER>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&em8_kernel<K, GATHER, WEIGHTED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((em8_kernel<K, GATHER>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((em8_kernel<K, GATHER, WEIGHTED>), dim3(grid), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -870,7 +886,7 @@ hipError_t launch_em8(int k, int grid, const PassArgs &a, hipStream_t s) {
     const bool gather = a.rows != nullptr;
 #define PPCA_E8_CASE(KK) \
     case KK:             \
-        return gather ? launch_em8_t<KK, true>(grid, a, s) : launch_em8_t<KK, false>(grid, a, s);
+        return gather ? launch_em8_t<KK, true, true>(grid, a, s) : (a.w ? launch_em8_t<KK, false, true>(grid, a, s) : launch_em8_t<KK, false, false>(grid, a, s));
     switch (k) {
 #ifdef PPCA_DEV_K10
         PPCA_E8_CASE(10)

@@ -219,25 +219,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // products, and the mask / centring is a compare and a select on the way.  Samples are cut into slices (grid.x), the
 // slice partials summed in slice order (deterministic).
 typedef double sd4_t __attribute__((ext_vector_type(4)));
-template <int NT>
-__global__ __launch_bounds__(256) void skinny_xt_kernel(const double *X, int64_t ldx, int64_t n, int d, const double *mean,
-                                                        const double *Bz, int ncols, int64_t rows_per_slice, double *part) {
+// NT = 16-column tiles of [wz | w], RT = 16-dimension row tiles per wave: a workgroup covers 256 dimensions with
+// 16 / RT waves (RT = 4: four waves, k + 1 <= 32; RT = 2: eight waves, k + 1 <= 80 -- 2 x RT x NT accumulator tiles).
+template <int NT, int RT>
+__global__ __launch_bounds__(64 * (16 / RT)) void skinny_xt_kernel(const double *X, int64_t ldx, int64_t n, int d, const double *mean,
+                                                                 const double *Bz, int ncols, int64_t rows_per_slice, double *part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int dbase = blockIdx.y * 256 + 64 * wave;
+    const int dbase = blockIdx.y * 256 + 16 * RT * wave;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slice, r1 = r0 + rows_per_slice < n ? r0 + rows_per_slice : n;
-    sd4_t accM[4][NT], accX[4][NT];
+    sd4_t accM[RT][NT], accX[RT][NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) accM[r][t] = accX[r][t] = sd4_t{0, 0, 0, 0};
     // Every load is unconditional (clamped to a real element) and the validity applied by selects afterwards: a load
     // inside a divergent branch gets its own exec-masked region and wait, and the loop turns latency-bound.
-    double mu[4];
-    bool dok[4];
-    int coff[4];
+    double mu[RT];
+    bool dok[RT];
+    int coff[RT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RT; ++r) {
         const int j = dbase + 16 * r + l15;
         dok[r] = j < d;
         coff[r] = dok[r] ? j : d - 1;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void skinny_xt_kernel(const double *X, int64_t
     }
     constexpr int UN = 4;  // k-steps (of four samples) whose operands are requested before the first of them is used
     for (int64_t s0 = r0; s0 < r1; s0 += 4 * UN) {
-        double xv[UN][4], bv[UN][NT];
+        double xv[UN][RT], bv[UN][NT];
         bool valid[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -261,15 +263,15 @@ __global__ __launch_bounds__(256) void skinny_xt_kernel(const double *X, int64_t
             valid[u] = row < r1;
             const int64_t rc = valid[u] ? row : r1 - 1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xv[u][r] = X[rc * ldx + coff[r]];
+            for (int r = 0; r < RT; ++r) xv[u][r] = X[rc * ldx + coff[r]];
 #pragma unroll
             for (int t = 0; t < NT; ++t) bv[u][t] = Bz[rc * ncols + boff[t]];
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            double am[4], xt[4], bz[NT];
+            double am[RT], xt[RT], bz[NT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RT; ++r) {
                 const bool ob = valid[u] && dok[r] && __builtin_fabs(xv[u][r]) < __builtin_inf();
                 am[r] = ob ? 1.0 : 0.0;
                 xt[r] = ob ? xv[u][r] - mu[r] : 0.0;  // select, never multiply (utils.rs:118-127)
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void skinny_xt_kernel(const double *X, int64_t
 #pragma unroll
             for (int t = 0; t < NT; ++t) bz[t] = (valid[u] && bok[t]) ? bv[u][t] : 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RT; ++r)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     accM[r][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[r], bz[t], accM[r][t], 0, 0, 0);
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256) void skinny_xt_kernel(const double *X, int64_t
     const int dpad = gridDim.y * 256;
     double *pm = part + ((int64_t)blockIdx.x * 2) * dpad * (16 * NT), *px = pm + (int64_t)dpad * (16 * NT);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t dim = dbase + 16 * r + l4 + 4 * q;
@@ -315,13 +317,13 @@ __global__ void skinny_xt_reduce_kernel(const double *part, int nslices, int dpa
     double *dst = prod == 0 ? (c < k ? U + (int64_t)dim * k + c : totals + dim) : (c < k ? cross + (int64_t)dim * k + c : sumx + dim);
     *dst += v;
 }
-// returns false when the shape is not the skinny kernel's (k + 1 > 32 columns or not enough scratch): the caller falls
+// returns false when the shape is not the skinny kernel's (k + 1 > 80 columns or not enough scratch): the caller falls
 // back on gemm_kernel<2> / <3>
 static bool launch_skinny_xt(const double *X, int64_t ldx, int64_t n, int d, int k, const double *mean, const double *Bz,
                              double *stats, const StatsLayout &L, double *part_ws, int64_t part_cap, int n_cu, hipStream_t s,
                              hipError_t *err) {
     const int ncols = k + 1, nt = (ncols + 15) / 16;
-    if (nt > 2 || n < 1) return false;
+    if (nt > 5 || n < 1) return false;
     const int gy = (d + 255) / 256, dpad = gy * 256, ncolpad = 16 * nt;
     int64_t slices = std::max<int64_t>(1, (4 * (int64_t)n_cu) / gy);   // four workgroups per CU: the loads of one cover the MFMAs of another
     slices = std::min<int64_t>(slices, (n + 255) / 256);
@@ -330,8 +332,13 @@ static bool launch_skinny_xt(const double *X, int64_t ldx, int64_t n, int d, int
     const int64_t rps = ((n + slices - 1) / slices + 3) / 4 * 4;
     slices = (n + rps - 1) / rps;
     dim3 grid((unsigned)slices, (unsigned)gy);
-    if (nt == 1) hipLaunchKernelGGL((skinny_xt_kernel<1>), grid, dim3(256), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws);
-    else hipLaunchKernelGGL((skinny_xt_kernel<2>), grid, dim3(256), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((skinny_xt_kernel<1, 4>), grid, dim3(256), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws); break;
+        case 2: hipLaunchKernelGGL((skinny_xt_kernel<2, 4>), grid, dim3(256), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws); break;
+        case 3: hipLaunchKernelGGL((skinny_xt_kernel<3, 2>), grid, dim3(512), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws); break;
+        case 4: hipLaunchKernelGGL((skinny_xt_kernel<4, 2>), grid, dim3(512), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws); break;
+        default: hipLaunchKernelGGL((skinny_xt_kernel<5, 2>), grid, dim3(512), 0, s, X, ldx, n, d, mean, Bz, ncols, rps, part_ws); break;
+    }
     const int64_t tot = 2 * (int64_t)dpad * ncolpad;
     hipLaunchKernelGGL(skinny_xt_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, part_ws, (int)slices, dpad, ncolpad, d, k,
                        stats + L.U, stats + L.totals, stats + L.cross, stats + L.sumx);
@@ -569,16 +576,28 @@ struct I8GemmArgs {
 // no vector address arithmetic in the K loop -- the pointer form spent 2.7 vector instructions per MFMA on 64-bit
 // addresses and bounds, SQ_INSTS_VALU 338 M against SQ_INSTS_MFMA 91 M per launch); needs both operands < 2 GiB.
 #ifndef I8_STAGES
-#define I8_STAGES 2  // measured at config 4: 1 -> 254.0, 2 -> 253.4, 3 -> 253.2, 4 -> 262.4 ms (spills)
+#define I8_STAGES 1  // measured at config 4 (round 2): 1 -> 254.0, 2 -> 253.4, 3 -> 253.2, 4 -> 262.4 ms (spills); the registers go to the fragments
 #endif
 template <int KB, int TM = 128, bool BUF = true>
 __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // two waves per SIMD (<= 256 registers): measured 64 vs 76 ms per iteration at 1 wave, 118 ms at 3 (spills)
     constexpr int THREADS = 2 * TM;
-    constexpr int RS = KB + 16, PR = KB / 16;           // LDS row stride, 16-byte pieces per row
+    constexpr int PR = KB / 16;                         // 16-byte pieces per row of a K-step
     constexpr int NA = TM * PR / THREADS, NB = GQS * 32 * PR / THREADS;  // pieces per thread
+    static_assert(KB == 64, "the LDS swizzle below is written for four pieces per row");
+    // LDS image of a K-step: PIECE-major, [4 pieces][rows][16 B], the row's low four bits XORed with g(piece) =
+    // {0, 2, 12, 14}.  ds_read_b128 serves a wave in four groups of 16 lanes -- rows {0-3, 12-15} of piece p with rows
+    // 4-11 of piece p + 1 -- and ds_write_b128 in groups of 8 lanes (two rows x four pieces here): with this image
+    // both hit 16 (8) different 16-byte slots.  The row-major image with 80-byte rows it replaces had two-way
+    // conflicts on the reads (5 r + p collides between the two halves of a group): SQ_LDS_BANK_CONFLICT was
+    // 0.9-1.1e9 against SQ_ACTIVE_INST_LDS 0.4-0.6e9 per launch (round 2, gpurun_out/pmcgen).
     extern __shared__ __attribute__((aligned(16))) unsigned char i8sm[];
-    unsigned char *As = i8sm;                              // [2][TM][RS]
-    unsigned char *Bs = i8sm + 2 * TM * RS;                // [2][GQS * 32][RS]
+    constexpr int AROWS = TM, BROWS = GQS * 32;
+    unsigned char *As = i8sm;                              // [2][4][TM][16]
+    unsigned char *Bs = i8sm + 2 * 4 * AROWS * 16;         // [2][4][GQS * 32][16]
+    auto slot = [](int rows, int buf, int row, int q) {    // byte offset of (row, piece q) in buffer buf
+        const int g = (q & 1) * 2 + (q >> 1) * 12;         // 0, 2, 12, 14
+        return ((buf * 4 + q) * rows + (row ^ g)) * 16;
+    };
     if (g.guard && *g.guard != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -657,30 +676,28 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int piece = tid + THREADS * u;
-            *reinterpret_cast<gi4_t *>(As + (buf * TM + piece / PR) * RS + 16 * (piece % PR)) = ra[st][u];
+            *reinterpret_cast<gi4_t *>(As + slot(AROWS, buf, piece / PR, piece % PR)) = ra[st][u];
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int piece = tid + THREADS * u;
-            *reinterpret_cast<gi4_t *>(Bs + (buf * GQS * 32 + piece / PR) * RS + 16 * (piece % PR)) = rb[st][u];
+            *reinterpret_cast<gi4_t *>(Bs + slot(BROWS, buf, piece / PR, piece % PR)) = rb[st][u];
         }
     };
     auto compute = [&](int buf) {
+        // every fragment of the K-step is requested before the first MFMA (12 reads in flight: the LDS latency is paid
+        // once per step, not once per slice pair as hipcc schedules the interleaved form)
+        gi4_t fa[4], fb[GQS];
 #pragma unroll
-        for (int h = 0; h < KB / 64; ++h) {
-            gi4_t fa[4];
+        for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const gi4_t *>(As + slot(AROWS, buf, 64 * wm + 16 * a + l15, l4));
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                fa[a] = *reinterpret_cast<const gi4_t *>(As + (buf * TM + 64 * wm + 16 * a + l15) * RS + 64 * h + 16 * l4);
+        for (int s = 0; s < GQS; ++s) fb[s] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, buf, s * 32 + 16 * wn + l15, l4));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < GQS; ++s) {
-                const gi4_t fb =
-                    *reinterpret_cast<const gi4_t *>(Bs + (buf * GQS * 32 + s * 32 + 16 * wn + l15) * RS + 64 * h + 16 * l4);
+        for (int s = 0; s < GQS; ++s)
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb, acc[a][s], 0, 0, 0);
-            }
-        }
+            for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (BUF) {
         // ST K-steps travel in registers while one is contracted out of LDS: a step is requested ST iterations (ST x
@@ -1873,7 +1890,7 @@ __global__ void add_partial_kernel(double *out, int64_t ldo, const double *part,
 
 template <int TM, bool BUF>
 static hipError_t launch_i8gemm_t(const I8GemmArgs &g, dim3 grid, hipStream_t s) {
-    const size_t lds = 2 * (TM + GQS * 32) * (64 + 16);
+    const size_t lds = 2 * (TM + GQS * 32) * 64;
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;

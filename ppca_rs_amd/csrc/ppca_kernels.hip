@@ -1703,18 +1703,6 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
 #endif
 }
 
-// Waves per workgroup of the EM pass: 4 (one per SIMD, 512 registers each).  PPCA_FUSED_WAVES=8 selects the
-// two-waves-per-SIMD variant (fp64-MFMA Gram), kept as a measured alternative: 182 vs 357 EM it/s at N = 2 M at the
-// end of round 1 -- the per-sample solve spills at 256 registers and both waves of a SIMD sit in the same phase, so
-// there is no MFMA time for the other's vector work to hide in.  PPCA_GRAM_FP64=1 (fp64-MFMA Gram, 4 waves): 240.
-static int em_waves() {
-    static const int nw = [] {
-        const char *e = getenv("PPCA_FUSED_WAVES");
-        return (e && atoi(e) == 8) ? 8 : 4;
-    }();
-    return nw;
-}
-
 #ifdef PPCA_DEV_K10
 // kernel-tuning builds (tools/devbuild.py): only the k = 10 int8-Gram variants are instantiated
 #define PPCA_DISPATCH_K(k, EXPR)                         \
@@ -1740,17 +1728,9 @@ static int em_waves() {
 #endif
 
 hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
-#ifdef PPCA_DEV_K10
+    // (the eight-wave fp64-Gram instantiation of pass_kernel that PPCA_FUSED_WAVES=8 used to select is gone: it ignored
+    //  PassArgs::rows, and the eight-wave kernel of this library is ppca_em8.hip)
     PPCA_DISPATCH_K(k, return (launch_pass_guarded<KK, true>(grid, a, s)));
-#else
-    if (em_waves() == 8) {
-        PassArgs b = a;
-        b.qflag = nullptr;
-        PPCA_DISPATCH_K(k, return (launch_pass_t<KK, true, 8, false>(grid, b, s)));
-    } else {
-        PPCA_DISPATCH_K(k, return (launch_pass_guarded<KK, true>(grid, a, s)));
-    }
-#endif
     return hipErrorInvalidValue;
 }
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s) {
