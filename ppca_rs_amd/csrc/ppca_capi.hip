@@ -213,7 +213,7 @@ static int d2h_pipelined(ppca_ctx *ctx, double *dst, const double *src, size_t n
             if (int rc = ensure(ctx->canon[b], ctx->canon_cap[b], CHUNK * sizeof(double))) return rc;
     const size_t nch = (n + CHUNK - 1) / CHUNK;
     unsigned hw = std::thread::hardware_concurrency();
-    int T = (int)std::min<unsigned>(8u, std::max<unsigned>(1u, hw / 2));
+    int T = (int)std::min<unsigned>(12u, std::max<unsigned>(1u, hw / 2));
     if (const char *e = getenv("PPCA_D2H_THREADS")) T = std::max(1, atoi(e));
     std::atomic<long> ready{0};
     std::atomic<bool> failed{false};

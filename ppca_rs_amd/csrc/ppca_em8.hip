@@ -51,6 +51,9 @@ constexpr int E8_HEAD = 6;      // binary orders kept free above the column maxi
 constexpr int E8_POISON = 100000;
 constexpr int E8_EMIN = -900, E8_EMAX = 1000;
 constexpr int E8_FLUSH_GROUPS = 100;
+#ifndef E8_BARRIER_SLEEP
+#define E8_BARRIER_SLEEP __builtin_amdgcn_s_sleep(1);
+#endif
 #ifndef E8_BACK_PRIO
 #define E8_BACK_PRIO 0
 #endif
@@ -102,7 +105,7 @@ __device__ __forceinline__ void role_barrier(unsigned *ctr, unsigned &target, in
     for (;;) {
         const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if ((int)(seen - target) >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
+        E8_BARRIER_SLEEP
     }
     asm volatile("" ::: "memory");
 }

@@ -1919,8 +1919,15 @@ static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
     const bool buf = !nobuf && g.K % 64 == 0 && (g.ksplit % 64) == 0 && g.M * g.lda < (int64_t(1) << 31) &&
                      GQS * g.plane < (int64_t(1) << 31);
     hipError_t e;
-    if (tm == 256 && g.ksplit == 0 && g.M >= 4096) {  // tall products (the Gram: one row per sample): 256-row tile
-        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 255) / 256), 1u);
+    // The 256-row tile also for the statistics product when it has >= 1024 rows (d >= 1024): its B operand -- the digit
+    // planes of wP, 8 bytes per entry like the fp64 values they stand for -- is re-read once per row block, so half
+    // as many row blocks halve the dominant operand traffic (config 4: 234.8 -> 222.6 ms).  PPCA_I8GEMM_S256=0: off.
+    static const bool s256 = [] {
+        const char *e = getenv("PPCA_I8GEMM_S256");
+        return !(e && atoi(e) == 0);
+    }();
+    if (tm == 256 && ((g.ksplit == 0 && g.M >= 4096) || (s256 && g.M >= 1024))) {  // tall products (the Gram: one row per sample): 256-row tile
+        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 255) / 256), g.ksplit > 0 ? (unsigned)g.nsplit : 1u);
         e = buf ? launch_i8gemm_t<256, true>(g, grid, s) : launch_i8gemm_t<256, false>(g, grid, s);
     } else {
         dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128), g.ksplit > 0 ? (unsigned)g.nsplit : 1u);
