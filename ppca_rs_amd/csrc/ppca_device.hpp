@@ -170,6 +170,12 @@ __device__ __forceinline__ d4_t mfma(double a, double b, d4_t c) {
 
 // ------------------------------------------------------------------ int8-sliced Gram operand (see ppca_kernels.hip)
 constexpr int QS = 8;
+// Digit width of the table: QB = 8 bits (balanced base 256, digits in [-128, 127]) since round 3 -- 62 bits below each
+// column maximum instead of the 54 of the 7-bit digits of rounds 1-2, at the same eight slices: the dynamic-range guard
+// admits 256 x smaller sigma^2 / row norms before it falls back on the fp64 engine.  Digit sums over 256 dims stay
+// below 2^15, a pair (hi * 2^QB + lo) below 2^24: exact in i32.
+constexpr int QB = 8;
+constexpr int QBASE = 1 << QB;
 typedef int i4_t __attribute__((ext_vector_type(4)));
 
 // Seven independent v_mfma_i32_16x16x64_i8 (one A operand, seven B operands, C = 0) with the results in VGPRs: the

@@ -615,8 +615,8 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int part = ia[1][r] * 128 + ia[0][r];
-                        v[rt2][r] = first ? (double)part : v[rt2][r] * 16384.0 + (double)part;
+                        const int part = ia[1][r] * QBASE + ia[0][r];
+                        v[rt2][r] = first ? (double)part : v[rt2][r] * (double)(QBASE * QBASE) + (double)part;
                     }
                 }
             };

@@ -30,22 +30,22 @@ namespace ppca {
 
 // ------------------------------------------------------------------ int8-sliced Gram operand
 // G_i = sum_j m_ij vech(c_j c_j^T) has one EXACT operand (the 0/1 mask), so the other one can be
-// split into QS signed 7-bit digits of a per-column fixed-point representation and contracted on
-// v_mfma_i32_16x16x64_i8 with exact integer accumulation:
-//   Q[j][c] = c_ja c_jb  ~  2^E_c 2^-(7 QS - 2) sum_s 128^s dig_s[j][c],   dig_s in [-64, 63],
-// E_c = exponent of max_j |Q[j][c]| (|Q| < 2^E_c).  QS balanced digits span (-0.504, +0.496) 128^QS, so
-// the integers are kept below 2^(7 QS - 2): with QS = 8 that is 54 bits under the column maximum,
-// finer than the fp64 rounding of the products themselves.
+// split into QS signed QB-bit digits (QB = 8 since round 3: balanced base 256; 7 in rounds 1-2) of a per-column
+// fixed-point representation and contracted on v_mfma_i32_16x16x64_i8 with exact integer accumulation:
+//   Q[j][c] = c_ja c_jb  ~  2^E_c 2^-(QB QS - 2) sum_s 256^s dig_s[j][c],   dig_s in [-128, 127],
+// E_c = exponent of max_j |Q[j][c]| (|Q| < 2^E_c).  QS balanced digits span (-0.502, +0.498) 256^QS, so
+// the integers are kept below 2^(QB QS - 2): with QS = 8 that is 62 bits under the column maximum -- every product
+// whose magnitude is within 2^9 of its column's largest is carried with its full fp64 mantissa.
 // qtab: [NTP][QS][4 k-chunks][64 lanes][16 bytes]; lane = 16 (dim/16 % 4) + (col % 16), byte = dim % 16
-// qscale: [64] dequantisation multipliers 2^(E_c - (7 QS - 2)).
+// qscale: [64] dequantisation multipliers 2^(E_c - (QB QS - 2)).
 // One workgroup per packed-column tile t (256 threads).  Step 1, thread = dim: maxima of the tile's 16 columns
 // (wave-level maximum first -- non-negative doubles order like their bit patterns -- then one LDS atomic per wave)
 // -> qscale.  Step 2, thread = (k-chunk, lane): 16 dims x one column, its 16 digits of every slice as one 16-byte
 // store per slice.  (Two launches before: a single-workgroup maximum over all 55 columns took 21 us per iteration.)
 //
 // Dynamic-range guard.  One scale per column means that a sample which masks the rows carrying the column maximum
-// gets a Gram summed from entries truncated at 2^(E_c - 55) each.  Per model (no knowledge of the masks) two
-// rigorous bounds are available, with eps = max_c 2^(E_c - 55), m' = observed rows with a non-zero c_j:
+// gets a Gram summed from entries truncated at 2^(E_c - 63) each.  Per model (no knowledge of the masks) two
+// rigorous bounds are available, with eps = max_c 2^(E_c - 63), m' = observed rows with a non-zero c_j:
 //   forward:   |dG|_F <= K m' eps  and  lambda_min(M_i) >= sigma^2  =>  |dM^-1| / |M^-1| <= K d eps / sigma^2
 //   backward:  |G_i|_2 >= tr(G_i) / K >= m' r_min / K  (r_min = smallest non-zero |c_j|^2)
 //                                                      =>  |dG|_F / |G_i|_2 <= K^2 eps / r_min
@@ -53,6 +53,9 @@ namespace ppca {
 // accumulation itself sits at ~2^-50 of |G_i|); otherwise -- or when a product is not finite / >= 1e300, which the
 // fixed-point form cannot carry -- qflag[tile] is raised and the launcher's fp64-MFMA instantiation of the pass
 // runs instead (both are enqueued, each returns at once unless the flag selects it: no host round trip).
+// With unit-scale C (column maxima ~ 2^4) the forward test passes down to sigma ~ 7e-4 and the backward test down to
+// row norms |c_j|^2 ~ 2e-4 of the scale (7-bit digits: 1e-2 and 5e-2): a trained model with a small sigma and a few
+// weakly loaded dimensions stays on the int8 engine.
 constexpr double QGUARD_FWD = 1.0e-8;
 constexpr double QGUARD_BWD = 9.094947017729282e-13;  // 2^-40
 
@@ -116,11 +119,11 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
         int e = 0;
         const double mx = __longlong_as_double((long long)cmax[j]);
         if (mx > 0.0) (void)frexp(mx, &e);
-        const double sc = ldexp(1.0, e - (7 * QS - 2));
+        const double sc = ldexp(1.0, e - (QB * QS - 2));
         scale[j] = sc;
         qscale[16 * t + j] = sc;
         if (mx > 0.0) {
-            const double eps = 0.5 * sc;  // rounding bound of one entry: 2^(E_c - 55)
+            const double eps = 0.5 * sc;  // rounding bound of one entry: 2^(E_c - 63)
             const double s2m = model[1], rmin = __longlong_as_double((long long)rmin_bits);
             const bool fwd = (double)K * (double)d * eps <= QGUARD_FWD * s2m;
             const bool bwd = (double)(K * K) * eps <= QGUARD_BWD * rmin;
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     const int b = c - a * (a + 1) / 2;
     const int j0 = 64 * kc + 16 * (lane >> 4);
     int ex = 0;
-    (void)frexp(scale[lane & 15], &ex);  // scale = 2^(E - (7 QS - 2)) = 0.5 * 2^(ex)
-    const int shift = -(ex - 1);         // multiply by 2^(7 QS - 2 - E)
+    (void)frexp(scale[lane & 15], &ex);  // scale = 2^(E - (QB QS - 2)) = 0.5 * 2^(ex)
+    const int shift = -(ex - 1);         // multiply by 2^(QB QS - 2 - E)
     union { signed char b8[QS][16]; i4_t v[QS]; } dg;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
@@ -149,11 +152,11 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
         double q = 0.0;
         if (c < KP && jd < d) q = model[MODEL_HDR + (int64_t)jd * K + a] * model[MODEL_HDR + (int64_t)jd * K + b];
         if (!(fabs(q) < 1.0e300)) q = 0.0;
-        long long I = llrint(ldexp(q, shift));  // |I| <= 2^(7 QS - 2)
+        long long I = llrint(ldexp(q, shift));  // |I| <= 2^(QB QS - 2)
 #pragma unroll
         for (int sl = 0; sl < QS; ++sl) {
-            const int dig = (int)((I + 64) & 127) - 64;
-            I = (I - dig) >> 7;
+            const int dig = (int)((I + QBASE / 2) & (QBASE - 1)) - QBASE / 2;
+            I = (I - dig) >> QB;
             dg.b8[sl][jj] = (signed char)dig;
         }
     }
@@ -556,8 +559,8 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int part = ia[1][r] * 128 + ia[0][r];
-                        v[rt2][r] = first ? (double)part : v[rt2][r] * 16384.0 + (double)part;
+                        const int part = ia[1][r] * QBASE + ia[0][r];
+                        v[rt2][r] = first ? (double)part : v[rt2][r] * (double)(QBASE * QBASE) + (double)part;
                     }
                 }
             };

@@ -637,7 +637,7 @@ def _engine(P, ds, m):
 
 
 def test_int8_gram_dynamic_range_guard(P, oracle):
-    """The int8-sliced Gram keeps 54 bits below each column maximum of vech(c c^T); when a sample masks the rows that
+    """The int8-sliced Gram keeps 62 bits below each column maximum of vech(c c^T); when a sample masks the rows that
     set the maximum, its Gram would be summed from truncated entries.  qprep's guard must send such models to the
     fp64-MFMA Gram on the device (output_covariance.rs:57-70 computes C_o^T C_o in f64), and keep the benign ones on
     the int8 engine."""
@@ -718,6 +718,47 @@ def test_int8_gram_dynamic_range_guard(P, oracle):
     mn = P.PPCAModel(0.5, cn, mu)
     assert _engine(P, P.Dataset(x0), mn) == 1
     assert not np.isfinite(mn.llk(P.Dataset(x0)))
+    # (d) what a trained model looks like -- sigma = 1e-3 of the scale and one weakly loaded dimension (row norm 1e-2 of
+    # the others) -- stays on the int8 engine (8-bit digits: 62 bits under each column maximum; the 7-bit digits of rounds
+    # 1-2 sent it to the fp64 engine) and agrees with a long-double dense evaluation of the posterior mean and the
+    # log-likelihood (the oracle's subtractive Woodbury form has ~7 digits left at |G| / sigma^2 ~ 2e9)
+    cd = rng.standard_normal((d, k))
+    cd[5] *= 1.0e-2
+    sd = 1.0e-3
+    xd = rng.standard_normal((n, k)) @ cd.T + mu + sd * rng.standard_normal((n, d))
+    xd[rng.random((n, d)) < 0.3] = np.nan
+    md, dsd = P.PPCAModel(sd, cd, mu), P.Dataset(xd)
+    assert _engine(P, dsd, md) == 0
+    zs, lls = md.infer(dsd).states(), md.llks(dsd)
+    ld = np.longdouble
+    wz = wl = 0.0
+    for i in list(range(0, 30)) + list(range(n - 30, n)):
+        o = np.isfinite(xd[i])
+        co = cd[o].astype(ld)
+        M = co.T @ co + ld(sd) ** 2 * np.eye(k, dtype=ld)
+        xt = (xd[i, o] - mu[o]).astype(ld)
+        b = co.T @ xt
+        Lc = np.zeros((k, k), dtype=ld)
+        for a in range(k):
+            for bb in range(a + 1):
+                v = M[a, bb] - (Lc[a, :bb] * Lc[bb, :bb]).sum()
+                Lc[a, bb] = np.sqrt(v) if a == bb else v / Lc[bb, bb]
+        y = np.zeros(k, dtype=ld)
+        for a in range(k):
+            y[a] = (b[a] - (Lc[a, :a] * y[:a]).sum()) / Lc[a, a]
+        zz = np.zeros(k, dtype=ld)
+        for a in reversed(range(k)):
+            zz[a] = (y[a] - (Lc[a + 1:, a] * zz[a + 1:]).sum()) / Lc[a, a]
+        mo = int(o.sum())
+        # (|x~|^2 - b^T M^-1 b) / s^2 = |x~ - C_o z|^2 / s^2 + |z|^2 without the cancellation (ppca_model.rs:124-139)
+        r = xt - co @ zz
+        llk_i = -ld(0.5) * ((r * r).sum() / ld(sd) ** 2 + (zz * zz).sum() + 2 * np.log(np.diag(Lc)).sum()
+                            + 2 * np.log(ld(sd)) * (mo - k) + np.log(2 * ld(np.pi)) * mo)
+        wz = max(wz, float(np.abs(zs[i] - zz.astype(np.float64)).max() / max(np.abs(zz).max(), 1e-300)))
+        wl = max(wl, abs(float(lls[i]) - float(llk_i)) / abs(float(llk_i)))
+    # (the llk's (|x~|^2 - b^T M^-1 b) / sigma^2 is a difference of two numbers ~1e7 times its size at this sigma, in the
+    #  reference's quadratic_form as here: 1e-7 is what fp64 leaves of it)
+    assert wz < 1e-9 and wl < 1e-7, (wz, wl)
 
 
 def test_library_rccl_communicator_single_rank(P, oracle):
