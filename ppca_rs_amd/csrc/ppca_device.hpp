@@ -42,7 +42,7 @@ struct Cfg {
     static constexpr int OFF_E = OFF_P1 + B * (K + 1);
     static constexpr int LDS_DOUBLES = OFF_E + 16 * NTM + 2;
     static constexpr int OFF_MB = OFF_L + 14 * B;  // 4 waves use L[0 .. 14 B); 256 u64 fit in [14 B, 22 B)
-    static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget");
+    static_assert(K > FUSED_MAX_K || LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget");  // (k > 10: only KP / NTP are used, by qprep_kernel)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -181,9 +181,13 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 // Seven independent v_mfma_i32_16x16x64_i8 (one A operand, seven B operands, C = 0) with the results in VGPRs: the
 // builtin's results land in accumulation registers, and under this kernel's register pressure all seven shared one
 // quad -- every MFMA waited for the previous result to be copied out.  The trailing s_nops cover the read-after-MFMA
-// wait states of the last result (the compiler does not see inside the statement).
+// wait states of the last result (the compiler does not see inside the statement); the leading s_nop 1 covers a VALU
+// write of an A / B operand register by the instruction just before the statement (hipcc pads nothing across the
+// boundary: seen as plane-0 digit sums of the first block contracted under a half-written mask operand, 1e-10 of S, in
+// ppca_em16.hip's instantiations for k = 11..15).
 __device__ __forceinline__ void mfma_i8_x7(const i4_t &a, const i4_t (&b)[7], i4_t (&d)[7]) {
     asm volatile(
+        "s_nop 1\n\t"
         "v_mfma_i32_16x16x64_i8 %0, %7, %8, 0\n\t"
         "v_mfma_i32_16x16x64_i8 %1, %7, %9, 0\n\t"
         "v_mfma_i32_16x16x64_i8 %2, %7, %10, 0\n\t"
@@ -199,6 +203,7 @@ __device__ __forceinline__ void mfma_i8_x7(const i4_t &a, const i4_t (&b)[7], i4
 // Three / one independent v_mfma_i32_16x16x64_i8 with a shared A operand (C = 0), results in VGPRs (see mfma_i8_x7).
 __device__ __forceinline__ void mfma_i8_x3(const i4_t &a, const i4_t &b0, const i4_t &b1, const i4_t &b2, i4_t &d0, i4_t &d1, i4_t &d2) {
     asm volatile(
+        "s_nop 1\n\t"
         "v_mfma_i32_16x16x64_i8 %0, %3, %4, 0\n\t"
         "v_mfma_i32_16x16x64_i8 %1, %3, %5, 0\n\t"
         "v_mfma_i32_16x16x64_i8 %2, %3, %6, 0\n\t"
@@ -208,6 +213,7 @@ __device__ __forceinline__ void mfma_i8_x3(const i4_t &a, const i4_t &b0, const 
 }
 __device__ __forceinline__ void mfma_i8_x1(const i4_t &a, const i4_t &b0, i4_t &d0) {
     asm volatile(
+        "s_nop 1\n\t"
         "v_mfma_i32_16x16x64_i8 %0, %1, %2, 0\n\t"
         "s_nop 7"
         : "=&v"(d0)

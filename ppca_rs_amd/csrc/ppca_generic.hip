@@ -1799,6 +1799,10 @@ static int64_t gen_chunk(int k) {
     int64_t c = (int64_t)(1.5e9 / (8.0 * (double)(kp + k + 8)));  // ~1.5 GB of per-sample workspace
     if (c > (1 << 20)) c = 1 << 20;
     if (c < 4096) c = 4096;
+    if (const char *e = getenv("PPCA_GEN_CHUNK")) {  // tests: several chunks at small N (a multiple of 64)
+        const int64_t v = atoll(e);
+        if (v >= 64) c = v / 64 * 64;
+    }
     return c;
 }
 
@@ -1822,7 +1826,12 @@ struct GenWs {
     int *flags;
     int dpad;
     int64_t npad;
+    // two-kernel EM pass for 11 <= k <= 16, d <= 256 (ppca_em16.hip): rows handed between the kernels, tile masks,
+    // per-workgroup partial statistics, [160 scales | 16 guard flags + 1 | slice table]
+    double *e16_W, *e16_part, *e16_q;
+    unsigned *e16_Mb;
 };
+constexpr int E16_MAX_GRID = 512;
 static size_t carve_impl(void *ws, int d, int k, int64_t n, GenWs *out) {
     const int64_t kp = (int64_t)k * (k + 1) / 2;
     GenWs w{};
@@ -1853,6 +1862,13 @@ static size_t carve_impl(void *ws, int d, int k, int64_t n, GenWs *out) {
     w.rmin = static_cast<double *>(take(256));
     w.spart = static_cast<double *>(take(sizeof(double) * 5 * (size_t)((w.chunk + SCAL_ROWS - 1) / SCAL_ROWS)));
     w.flags = static_cast<int *>(take(256));
+    if (em16_covers(d, k)) {
+        const StatsLayout L(d, k);
+        w.e16_W = static_cast<double *>(take(sizeof(double) * (size_t)w.chunk * em16_ncol(k)));
+        w.e16_Mb = static_cast<unsigned *>(take(sizeof(unsigned) * 256 * (size_t)((w.chunk + 31) / 32)));
+        w.e16_part = static_cast<double *>(take(sizeof(double) * (size_t)E16_MAX_GRID * L.len));
+        w.e16_q = static_cast<double *>(take(sizeof(double) * 192 + em16_qtab_bytes(k)));
+    }
     if (out) *out = w;
     return off;
 }
@@ -2014,6 +2030,60 @@ static hipError_t set_solve_lds(int k) {
     } while (0)
 
 // E-step + statistics of all rows into stats (overwritten).  post == true: only the solve outputs.
+// PPCA_EM16=0: the split pipeline below also for 11 <= k <= 16, d <= 256 (A/B runs against ppca_em16.hip)
+static bool em16_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_EM16");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+__global__ void flag_any_kernel(const int *flags, int nflags, int *out) {
+    int any = 0;
+    for (int i = 0; i < nflags; ++i) any |= flags[i];
+    *out = any ? 1 : 0;
+}
+
+// The EM pass for 11 <= k <= 16, d <= 256: per chunk, the fused E-step kernel and the mask-side statistics kernel of
+// ppca_em16.hip (int8-sliced Gram behind the dynamic-range guard; a model that trips it gets its Gram rows from the
+// fp64 product below, a guarded launch that otherwise returns at once), partial statistics summed into `stats`.
+static hipError_t run_em16(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k, const double *model,
+                           double *stats, const GenWs &W, int n_cu, hipStream_t s) {
+    const int64_t kp = (int64_t)k * (k + 1) / 2;
+    const StatsLayout L(d, k);
+    const int ntp = (int)((kp + 15) / 16);
+    double *qscale = W.e16_q;
+    int *qflag = reinterpret_cast<int *>(qscale + 160);
+    int *anyflag = qflag + 16;
+    signed char *qtab = reinterpret_cast<signed char *>(qscale + 192);
+    GTRY(launch_qprep16(k, model, d, qscale, qtab, qflag, s));
+    hipLaunchKernelGGL(flag_any_kernel, dim3(1), dim3(1), 0, s, qflag, ntp, anyflag);
+    {
+        const int64_t tot = (int64_t)d * kp;
+        hipLaunchKernelGGL(qtab_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, model, d, k, W.Q);
+        GTRY(hipGetLastError());
+    }
+    for (int64_t r0 = 0; r0 < n; r0 += W.chunk) {
+        const int64_t nc = std::min(W.chunk, n - r0);
+        const double *Xc = X + r0 * ldx;
+        GemmArgs g{};
+        g.X = Xc; g.ldx = ldx; g.mean = model + MODEL_HDR + (int64_t)d * k;
+        g.B = W.Q; g.ldb = kp; g.M = nc; g.N = kp; g.K = d;
+        g.out0 = W.G; g.ld0 = kp; g.ncols0 = kp; g.out1 = nullptr; g.ld1 = 0; g.accumulate = 0;
+        g.guard = anyflag; g.run_if = 1;
+        GTRY(launch_gemm<0>(g, s, n_cu, nullptr, 0));
+        int grid = fused_grid(nc, n_cu);
+        if (grid > E16_MAX_GRID) grid = E16_MAX_GRID;
+        Em16Launch a{};
+        a.X = Xc; a.ldx = ldx; a.w = w ? w + r0 : nullptr; a.n = nc; a.d = d; a.model = model;
+        a.part = W.e16_part; a.qtab = qtab; a.qscale = qscale; a.qflag = qflag; a.Gext = W.G;
+        a.Wrows = W.e16_W; a.Mb = W.e16_Mb; a.no_llk = 0; a.dbg = nullptr;
+        GTRY(launch_em16(k, grid, a, s));
+        GTRY(launch_reduce_partials(W.e16_part, grid, L.len, stats, s, r0 > 0 ? 1 : 0));
+    }
+    return hipSuccess;
+}
+
 static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k,
                               const double *model, bool em, double *stats,
                               double *scal8, double *llks, double *states, double *covs, double *recon, int recon_mode,
@@ -2024,6 +2094,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
     const double *mean = model + MODEL_HDR + (int64_t)d * k;
     const double *Cm = model + MODEL_HDR;
     const bool i8 = generic_i8();
+    if (em && i8 && em16_enabled() && em16_covers(d, k)) return run_em16(X, ldx, w, n, d, k, model, stats, W, n_cu, s);
     {
         const int64_t tot = (int64_t)d * kp;
         hipLaunchKernelGGL(qtab_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, model, d, k, W.Q);
@@ -2164,6 +2235,14 @@ hipError_t generic_gram_guard(int d, int k, const double *model, void *ws, hipSt
     *forced = -1;
     const int64_t kp = (int64_t)k * (k + 1) / 2;
     GenWs W = carve(ws, d, k, 1);
+    if (em16_enabled() && em16_covers(d, k)) {  // the EM pass of these shapes: the guard of its own slice table (ppca_em16.hip)
+        double *qscale = W.e16_q;
+        int *qflag = reinterpret_cast<int *>(qscale + 160);
+        GTRY(launch_qprep16(k, model, d, qscale, reinterpret_cast<signed char *>(qscale + 192), qflag, s));
+        hipLaunchKernelGGL(flag_any_kernel, dim3(1), dim3(1), 0, s, qflag, (int)((kp + 15) / 16), qflag + 16);
+        *flag_dev = qflag + 16;
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gen_rmin_kernel, dim3(1), dim3(256), 0, s, model, d, k, W.rmin, W.flags);
     hipLaunchKernelGGL(gen_qdigits_kernel, dim3((unsigned)kp), dim3(256), 0, s, model, d, k, W.dpad, (int)kp, W.rmin, W.scaleQ, W.BtQ,
                        W.flags);

@@ -64,10 +64,35 @@ hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);
 // waves contract the mask-side statistics on the int8 MFMA.  Honours a.qflag like the int8 instantiation of pass_kernel.
 bool em8_covers(int k);
 hipError_t launch_em8(int k, int grid, const PassArgs &a, hipStream_t s);
+// The EM pass for 11 <= k <= 16, d <= 256 as two fused kernels (ppca_em16.hip): E-step sweep over X writing the rows
+// [wP | wz | w] and the tiles' sample masks, then the mask-side statistics on the int8 MFMA.  Both write disjoint parts of
+// part[grid][stats_len] (reduce with launch_reduce_partials).
+struct Em16Launch {
+    const double *X;
+    int64_t ldx;
+    const double *w;       // nullable
+    int64_t n;
+    int d;
+    const double *model;
+    double *part;          // [grid][stats_len]
+    signed char *qtab;     // int8 Gram slice table of the model, em16_qtab_bytes(k) (launch_qprep16)
+    double *qscale;        // 16 x tiles dequantisation multipliers
+    int *qflag;            // [tiles] guard flags; any set -> the Gram rows are read from Gext
+    const double *Gext;    // [n][k'] packed Gram rows of the fp64 engine (read only when the guard tripped)
+    double *Wrows;         // [n][em16_ncol(k)] scratch: the rows handed from the first kernel to the second
+    unsigned *Mb;          // [ceil(n / 32)][256] scratch: per tile and dimension, the 32 sample bits
+    int no_llk;
+    double *dbg;
+};
+bool em16_covers(int d, int k);
+int em16_ncol(int k);
+size_t em16_qtab_bytes(int k);
+hipError_t launch_qprep16(int k, const double *model, int d, double *qscale, signed char *qtab, int *qflag, hipStream_t s);
+hipError_t launch_em16(int k, int grid, const Em16Launch &a, hipStream_t s);
 // The log-likelihood sweep alone (ppca_llk.hip): per-sample llks (nullable) and the per-workgroup scalars; honours
 // a.qflag like the int8 instantiation of pass_kernel.
 hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s);
-hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s);
+hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s, int accumulate = 0);
 hipError_t launch_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
                            int has_ig, double alpha, double beta, hipStream_t s);
 hipError_t launch_synth(const double *c_dev, const double *mean_dev, double *z_work, double *x_out, int64_t row_offset,

@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 // out[e] = sum over workgroup partials in a fixed order (deterministic): four threads per element
 // each sum a contiguous quarter of the partials, the quarters are combined as (q0 + q1) + (q2 + q3).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *part, int grid_parts, int64_t len,
-                                                             double *out) {
+                                                             double *out, int accumulate) {
     __shared__ double red[4][64];
     const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int64_t e = (int64_t)blockIdx.x * 64 + l;
@@ -1318,7 +1318,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *part
     }
     red[g][l] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (g == 0 && e < len) out[e] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (g == 0 && e < len) {
+        const double v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        out[e] = accumulate ? out[e] + v : v;
+    }
 }
 
 // M-step finalisation (ppca_model.rs:307-322, :360-377) -- one workgroup.
@@ -1754,11 +1757,24 @@ hipError_t launch_gram_guard(int k, const PassArgs &a, hipStream_t s, int *force
     return hipGetLastError();
 #endif
 }
+// slice table + guard flags for the state sizes of ppca_em16.hip
+hipError_t launch_qprep16(int k, const double *model, int d, double *qscale, signed char *qtab, int *qflag, hipStream_t s) {
+    switch (k) {
+#define PPCA_Q16(KK)                                                                                                  \
+    case KK:                                                                                                          \
+        hipLaunchKernelGGL((qprep_kernel<KK>), dim3(Cfg<KK>::NTP), dim3(256), 0, s, model, d, qscale, qtab, qflag); \
+        break;
+        PPCA_Q16(11) PPCA_Q16(12) PPCA_Q16(13) PPCA_Q16(14) PPCA_Q16(15) PPCA_Q16(16)
+#undef PPCA_Q16
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 int fused_gram_tiles(int k) { return (k * (k + 1) / 2 + 15) / 16; }
 
-hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s) {
+hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s, int accumulate) {
     int blocks = (int)((len + 63) / 64);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, part, grid_parts, len, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, part, grid_parts, len, out, accumulate);
     return hipGetLastError();
 }
 
