@@ -36,24 +36,35 @@ constexpr int E16_POISON = 100000;
 constexpr int E16_EMIN = -900, E16_EMAX = 1000;
 constexpr int E16_FLUSH_GROUPS = 100;
 constexpr int E16_MIN_K = 11, E16_MAX_K = 16;
+#ifndef E16_SPLIT_MIN_K
+#define E16_SPLIT_MIN_K 14
+#endif
 
 template <int K>
 struct Cfg16 {
     static constexpr int KP = K * (K + 1) / 2;
     static constexpr int NTP = (KP + 15) / 16;
-    static constexpr int B = 32, DP = 256, XS = DP + 2, CS = K + 1;
+    static constexpr int B = 32, DP = 256, XS = DP + 2;
+    // SPLIT: the per-sample solve with the factor split over lane pairs and parked in LDS (k >= 14: 105+ packed doubles
+    // and the solver's working set no longer fit a lane's 256 directly addressable registers) -- then C is read from
+    // L2 per tile and its place in LDS holds the factors; else the factor lives in registers and C in LDS
+    static constexpr bool SPLIT = K >= E16_SPLIT_MIN_K;
+    static constexpr int CS = K + 1;             // C tile row stride; column K is all zeros
+    static constexpr int LS = KP | 1;            // row stride of the factor buffer (odd: conflict-free per-lane rows)
     static constexpr int NC = KP + K + 1;        // statistic columns [wP | wz | w]
     static constexpr int NCT = (NC + 15) / 16;
     static constexpr int NCOL = 16 * NCT;        // row stride of the hand-over buffer (doubles)
     // ---- estep16_kernel
     // [G | b] and the [wP | wz | w] rows share ONE buffer (row stride GS), as in em8_kernel:
     //   as [G | b]:  G (16 NTP, K' used) | b partial of dims 0-127 (16) | pad
-    //   as W row:    wP (K') ..          | wz (K) | w | ..
+    //   as W row:    wP (K') | wz (K) | w | ..      (compact: the hand-over buffer's row)
     static constexpr int GS = 16 * NTP + 18;
+    static_assert(GS % 2 == 0 && GS >= NCOL, "W rows: 16-byte pieces, compact [wP | wz | w | pad] inside the row");
     static constexpr int BS = K + 1;             // b partial of dims 128-255
     static constexpr int OFF_X = 0;
-    static constexpr int OFF_C = OFF_X + B * XS;
-    static constexpr int OFF_G = OFF_C + DP * CS;
+    static constexpr int OFF_LB = OFF_X + B * XS;         // packed Cholesky factors of the tile's samples
+    static constexpr int OFF_C = OFF_LB;                  // ... or C (not SPLIT)
+    static constexpr int OFF_G = OFF_LB + (SPLIT ? B * LS : DP * CS);
     static constexpr int OFF_B1 = OFF_G + B * GS;
     static constexpr int OFF_M = OFF_B1 + B * BS;         // mask words, two parities x B x 4 u64
     static constexpr int OFF_MB = OFF_M + 2 * B * 4;      // sample masks per dimension of the staged tile: DP u32
@@ -84,18 +95,208 @@ struct S16Args {
     double *part;          // [grid][stats_len]: this kernel writes S, U, totals
 };
 
+#ifndef E16_STORE_MODE
+#define E16_STORE_MODE 0
+#endif
 #ifdef PPCA_PHASE_TIMING
 #define E16_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
 #else
 #define E16_STAMP(i)
 #endif
 
+// ------------------------------------------------------------------ the per-sample solve of estep16_kernel
+// Broadcast of one half of the wave to both: v_permlane32_swap with both operands the same register leaves
+// (lower | lower) in the first result and (upper | upper) in the second.
+template <int H>
+__device__ __forceinline__ double bcast_half(double x) {
+    const long long b = __double_as_longlong(x);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double(((long long)hi[H] << 32) | lo[H]);
+}
+
+// Cholesky factor of M = G + s2 I, split over the lane pair (lane, lane ^ 32): half h = lane >> 5 owns the columns
+// b = 2 j + h.  Slot (a, j), j <= a / 2, holds entry (a, 2 j + h) (half 1's slot (a, a / 2) of an even row a is unused
+// and never read).  Right-looking: per pivot column c its owner's entries are broadcast to both halves (two
+// v_permlane32_swap per double), then every half updates its own columns -- all multiply-adds independent.  The same
+// arithmetic per entry as Posterior<K>::factor_loaded (ppca_small.hpp): diagonal slots keep 1 / L_aa.
+template <int K>
+struct SplitChol {
+    static constexpr int off(int a) {
+        int s = 0;
+        for (int r = 0; r < a; ++r) s += r / 2 + 1;
+        return s;
+    }
+    static constexpr int idx(int a, int j) { return off(a) + j; }
+    static constexpr int NS = off(K);
+    double L[NS];
+
+    __device__ __forceinline__ void load(const double *g, int hi, double s2) {
+        const double *gh = g + hi;
+        static_for<K>([&](auto a_tag) {
+            constexpr int a = decltype(a_tag)::value;
+            static_for<a / 2 + 1>([&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+                double v = gh[tri(a, 2 * j)];  // entry (a, 2 j + hi): neighbours in the packed row
+                if constexpr (2 * j == a) v = hi ? 0.0 : v + s2;      // diagonal of an even row (half 0); half 1: unused slot
+                else if constexpr (2 * j + 1 == a) v = hi ? v + s2 : v;  // diagonal of an odd row (half 1)
+                L[idx(a, j)] = v;
+            });
+        });
+    }
+    __device__ __forceinline__ void factor(int hi, double &pm, int &pe) {
+        double grp[2] = {1.0, 1.0};
+        static_for<K>([&](auto c_tag) {
+            constexpr int c = decltype(c_tag)::value, hc = c & 1, jc = c >> 1;
+            const bool own = hi == hc;
+            const double piv = bcast_half<hc>(L[idx(c, jc)]);
+            grp[c >= (K + 1) / 2] *= piv;
+            const double inv = fast_rsqrt(piv);  // 1 / L_cc
+            L[idx(c, jc)] = own ? inv : L[idx(c, jc)];
+            if constexpr (c + 1 < K) {
+                double pc[K];
+#pragma unroll
+                for (int a = c + 1; a < K; ++a) {
+                    pc[a] = bcast_half<hc>(L[idx(a, jc)]) * inv;
+                    L[idx(a, jc)] = own ? pc[a] : L[idx(a, jc)];
+                }
+                // second factors of this half's columns: column 2 j + hi (the pivot column itself, in half 0 of an even
+                // step, gets a zero: its slots hold the scaled column already)
+                constexpr int jlo = hc ? jc + 1 : jc, jhi = (K - 1) / 2;
+                double ps[jhi + 1];
+#pragma unroll
+                for (int j = jlo; j <= jhi; ++j) {
+                    const double v0 = (2 * j > c) ? pc[2 * j] : 0.0;
+                    const double v1 = (2 * j + 1 < K) ? pc[2 * j + 1] : 0.0;
+                    ps[j] = hi ? v1 : v0;
+                }
+#pragma unroll
+                for (int a = c + 1; a < K; ++a)
+#pragma unroll
+                    for (int j = jlo; j <= a / 2; ++j) L[idx(a, j)] -= pc[a] * ps[j];
+            }
+        });
+        int e0, e1;
+        pm = frexp(grp[0], &e0) * frexp(grp[1], &e1);
+        pe = e0 + e1;
+    }
+    // the factor into the packed row (the four waves hold the same values: each writes the rows a = wave mod 4)
+    __device__ __forceinline__ void store(double *g, int hi, int wave) const {
+        double *gh = g + hi;
+        static_for<K>([&](auto a_tag) {
+            constexpr int a = decltype(a_tag)::value;
+            if ((a & 3) == wave) {
+                static_for<a / 2 + 1>([&](auto j_tag) {
+                    constexpr int j = decltype(j_tag)::value;
+                    if constexpr (2 * j == a) {
+                        if (!hi) gh[tri(a, 2 * j)] = L[idx(a, j)];
+                    } else {
+                        gh[tri(a, 2 * j)] = L[idx(a, j)];
+                    }
+                });
+            }
+        });
+    }
+};
+
+// The column pairs of M^-1 of worker w of 4 (every worker also solves for z, so the pairs alone are balanced): pair w
+// and its mirror 7 - w -- the costs, (K - 2 p)^2, fall with p, so heavy goes with light; -1: none.
+constexpr int first_pair(int w) { return w; }
+constexpr int second_pair(int K, int w) { return 7 - w < (K + 1) / 2 ? 7 - w : -1; }
+
+// z = M^-1 b (b in z), quad = b^T M^-1 b, zz = |z|^2 with the packed factor read from LDS (Posterior<K>::solve_loaded).
+// A substitution is a chain of K dependent steps, each needing one column (forward) or row (backward) of the factor:
+// the entries of the NEXT step are requested before the current step's arithmetic, so a step costs its multiply-adds,
+// not an LDS round trip (measured before: ~150 cycles per step, 32 steps per solve).
+template <int K>
+__device__ __forceinline__ void solve_lds(const double *Lr, double (&z)[K], double &quad, double &zz) {
+    double buf[2][K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) buf[0][a] = Lr[tri(a, 0)];
+    quad = 0.0;
+    static_for<K>([&](auto t_tag) {
+        constexpr int t = decltype(t_tag)::value;
+        if constexpr (t + 1 < K) {
+#pragma unroll
+            for (int a = t + 1; a < K; ++a) buf[(t + 1) & 1][a] = Lr[tri(a, t + 1)];
+        } else {
+#pragma unroll
+            for (int a = 0; a < K; ++a) buf[(t + 1) & 1][a] = Lr[tri(K - 1, a)];  // the first row of the backward pass
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        z[t] *= buf[t & 1][t];
+        quad += z[t] * z[t];
+#pragma unroll
+        for (int a = t + 1; a < K; ++a) z[a] -= buf[t & 1][a] * z[t];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    zz = 0.0;
+    static_for<K>([&](auto s_tag) {
+        constexpr int s = decltype(s_tag)::value, t = K - 1 - s, pb = (K + s) & 1;
+        if constexpr (t >= 1) {
+#pragma unroll
+            for (int a = 0; a < t; ++a) buf[pb ^ 1][a] = Lr[tri(t - 1, a)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        z[t] *= buf[pb][t];
+        zz += z[t] * z[t];
+#pragma unroll
+        for (int a = 0; a < t; ++a) z[a] -= buf[pb][a] * z[t];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+// Columns C0 (half 0) and C0 + 1 (half 1) of M^-1, rows t >= C0, factor read from LDS with the same one-step-ahead
+// requests (Posterior<K>::minv_column_pair); st(t, v): entry (t, C0 + hi).  Returns (M^-1) at (C0 + hi, C0 + hi).
+template <int K, int C0, class Store>
+__device__ __forceinline__ double minv_pair_lds(const double *Lr, int hi, Store st) {
+    double u[K];
+#pragma unroll
+    for (int a = C0; a < K; ++a) u[a] = (a == C0 + hi) ? 1.0 : 0.0;
+    double buf[2][K];
+#pragma unroll
+    for (int a = C0; a < K; ++a) buf[C0 & 1][a] = Lr[tri(a, C0)];
+    static_for<K - C0>([&](auto s_tag) {
+        constexpr int t = C0 + decltype(s_tag)::value;
+        if constexpr (t + 1 < K) {
+#pragma unroll
+            for (int a = t + 1; a < K; ++a) buf[(t + 1) & 1][a] = Lr[tri(a, t + 1)];
+        } else {
+#pragma unroll
+            for (int a = C0; a < K; ++a) buf[(t + 1) & 1][a] = Lr[tri(K - 1, a)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u[t] *= buf[t & 1][t];
+#pragma unroll
+        for (int a = t + 1; a < K; ++a) u[a] -= buf[t & 1][a] * u[t];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    double diag = 0.0;
+    static_for<K - C0>([&](auto s_tag) {
+        constexpr int s = decltype(s_tag)::value, t = K - 1 - s, pb = (K + s) & 1;
+        if constexpr (t - 1 >= C0) {
+#pragma unroll
+            for (int a = C0; a < t; ++a) buf[pb ^ 1][a] = Lr[tri(t - 1, a)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u[t] *= buf[pb][t];
+        st(t, u[t]);
+        if constexpr (t == C0 + 1) diag = hi ? u[t] : diag;
+        if constexpr (t == C0) diag = hi ? diag : u[t];
+#pragma unroll
+        for (int a = C0; a < t; ++a) u[a] -= buf[pb][a] * u[t];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    return diag;
+}
+
 // ===================================================================== E-step
 template <int K, bool WEIGHTED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void estep16_kernel(Em16Launch p) {
     using cfg = Cfg16<K>;
-    constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS, BS = cfg::BS,
+    constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, GS = cfg::GS, BS = cfg::BS, LS = cfg::LS,
                   WS = cfg::GS, NC = cfg::NC, NCOL = cfg::NCOL;
+    constexpr bool SPLIT = cfg::SPLIT;
+    constexpr int CS = cfg::CS;
     constexpr int NF = 4;
     constexpr int RPW = B / NF;        // rows staged per wave
     constexpr int DPS = cfg::DP / 2;   // dims per K-split of b = X~ C
@@ -106,6 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_assert(QS == 8, "digit grouping assumes 8 slices");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Xs = sm + cfg::OFF_X;
+    double *Lb = sm + cfg::OFF_LB;
     double *Cs = sm + cfg::OFF_C;
     double *Gs = sm + cfg::OFF_G;
     double *B1 = sm + cfg::OFF_B1;
@@ -127,9 +329,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int t = 0; t < NTP; ++t) unsafe |= p.qflag[t];
     unsafe = __builtin_amdgcn_readfirstlane(unsafe);
 
-    for (int idx = tid; idx < cfg::DP * CS; idx += 256) {
-        int j = idx / CS, a = idx - j * CS;
-        Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
+    if constexpr (!SPLIT) {
+        for (int idx = tid; idx < cfg::DP * CS; idx += 256) {
+            int j = idx / CS, a = idx - j * CS;
+            Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
+        }
     }
     constexpr int SQW = 2 * B;  // sq slots per wave (lane pairs)
     constexpr int L_DEV = NF * SQW, L_LLK = L_DEV + B, L_W = L_DEV + 2 * B, L_NE = L_DEV + 3 * B, L_PM = L_DEV + 4 * B,
@@ -151,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
     const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
 #ifdef PPCA_PHASE_TIMING
-    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
 #endif
     __syncthreads();
@@ -251,10 +455,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int q = 0; q < 4; ++q) mbb[(128 * (q >> 1) + 2 * lane + (q & 1)) * 4 + wave] = (unsigned char)st_mb[q];
     };
 
+    // Every workgroup does the same work per tile, so the chip's memory requests would come in bursts: the row loads
+    // (64 KB) and row stores (40 KB) of all 256 workgroups inside the same ~3 k cycles of a ~50 k-cycle tile period
+    // (measured: 7.4 k cycles for a 2.5 k-cycle phase).  A quarter-period start offset per workgroup spreads them.
+#ifndef E16_STAGGER
+#define E16_STAGGER 2
+#endif
+    for (int q = 0; q < (int)(blockIdx.x & 3) * E16_STAGGER; ++q) __builtin_amdgcn_s_sleep(96);
+    // B operand of b = X~ C: this wave's K-half of C (dims DPS kq + l4 + 4 u, column l15; zeros past d and past K).  The
+    // fragments do not depend on the tile, but as kernel-long register residents they were what the factorisation spilled
+    // (and their place in LDS holds the factors): they are requested from L2 behind the previous tile's P4a, arrive
+    // during the staging and die with the b product at the head of P2.
+    double cf[STEPS];
+    auto load_cf = [&](int lane) {
+        const int l15 = lane & 15, l4 = lane >> 4, kq = wave >> 1;
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            const int dim = DPS * kq + l4 + 4 * u;
+            const bool live = dim < d && l15 < K;
+            const double v = mC[live ? dim * K + l15 : 0];
+            cf[u] = live ? v : 0.0;
+        }
+    };
     if (tile_begin < tile_end) {
         const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile_begin);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) load_row(trs, r);
+        if constexpr (SPLIT) load_cf(lane_entry);
         stage_tile(tile_begin, lane_entry);
     }
     __syncthreads();
@@ -263,7 +490,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int lane = lane_entry;
         asm volatile("" : "+v"(lane));
         const int l15 = lane & 15, l4 = lane >> 4;
-        const int colb = (l15 < K) ? l15 : K;
         const int rel = (int)(tile - tile_begin);
         const unsigned long long *Msc = Ms + (rel & 1) * 4 * B;
         // ------------------------------------------------------------ P2: [G | b] of the tile
@@ -272,12 +498,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int si = 16 * rt + l15;
             d4_t accb = d4_t{0, 0, 0, 0};
             const double *xrow = Xs + si * XS + DPS * kq + l4;
-            const double *cpc = Cs + (DPS * kq + l4) * CS + colb;
             i4_t qb[2][2][4];
             if (!unsafe) load_pair(qb[0], wave, 6);  // (every wave owns at least one tile: NTP >= 4)
-            {
-                // b = X~ C: operands of the next four k-steps are requested before the current four MFMAs issue
+            if constexpr (SPLIT) {
+                // b = X~ C: the A operands of the next four k-steps are requested before the current four MFMAs issue
                 constexpr int CH = 4;
+                double axb[2][CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) axb[0][u] = xrow[4 * u];
+#pragma unroll
+                for (int c = 0; c < STEPS / CH; ++c) {
+                    if (c + 1 < STEPS / CH) {
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) accb = mfma(axb[c & 1][u], cf[c * CH + u], accb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                constexpr int CH = 4;
+                const double *cpc = Cs + (DPS * kq + l4) * CS + (l15 < K ? l15 : K);
                 double axb[2][CH], cbb[2][CH];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
@@ -299,6 +541,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            E16_STAMP(0)
             if (!unsafe) {
                 // int8-sliced Gram: A = mask bytes (lane: sample 16 rt2 + l15, k-chunk kc, dims 16 l4 .. +15 of it), B = the
                 // digit table of packed-column tile ti; tiles wave, wave + 4, wave + 8
@@ -351,11 +594,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else {
                 // the guard tripped: packed Gram rows of the fp64 engine (a guarded launch before this kernel)
                 const int64_t row0 = tile * B;
-                for (int idx = tid; idx < B * KP; idx += 256) {
+                for (int idx = 64 * wave + lane; idx < B * KP; idx += 256) {
                     const int r = idx / KP, e = idx - r * KP;
                     Gs[r * GS + e] = (row0 + r < n) ? p.Gext[(row0 + r) * KP + e] : 0.0;
                 }
             }
+            E16_STAMP(1)
             // the two K-split partials of b are summed by the solver in a fixed order (p0 + p1)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -364,25 +608,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         __syncthreads();
-        E16_STAMP(0)
+        E16_STAMP(2)
         // ------------------------------------------------------------ P3: per-sample k x k solve
-        // Every wave factors every sample (lane = sample, lanes 32-63 mirror 0-31) and the waves share the independent
-        // columns of M^-1, two per instruction stream; wave 0 also owns z, llk and the scalars.
+        // The packed Cholesky factor (136 doubles at k = 16) does not fit the 256 directly addressable registers of a
+        // lane: a lane-per-sample factorisation ran on register-file copies (9 x the arithmetic).  Here the lane pair
+        // (i, i + 32) holds the factor column-cyclically (SplitChol: 72 doubles each) and exchanges the pivot column
+        // per step; the finished factor goes to its own LDS buffer, and the substitutions -- z in every wave, the
+        // columns of M^-1 shared by the waves, two per instruction stream as in em8_kernel -- read it from there
+        // (same address in both halves: one broadcast read), writing the W rows over the Gram as they go.
         {
             const double s2 = sm[cfg::OFF_K], inv_s2 = sm[cfg::OFF_K + 1], lnsig = sm[cfg::OFF_K + 2];
             const int i = lane & (B - 1);
             const int hi = lane >> 5;
             const int64_t row = tile * B + i;
             const double *g0 = Gs + i * GS;
-            const double *b1 = B1 + i * BS;
+            double *b1 = B1 + i * BS;
+            double *lrow = Lb + i * LS;
             const double wgt = (row < n) ? (WEIGHTED ? p.w[row] : 1.0) : 0.0;
             const int m = __popcll(Msc[i * 4]) + __popcll(Msc[i * 4 + 1]) + __popcll(Msc[i * 4 + 2]) + __popcll(Msc[i * 4 + 3]);
             double *wrow = Ws + i * WS;
             double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;
-            Posterior<K> post;
+            double trpart = 0.0;
             double pm;
             int pe;
-            double z[K], quad, zz;
+            double z[K], quad = 0.0, zz = 0.0;
+            if constexpr (SPLIT) {
+            {
+                SplitChol<K> sc;
+                sc.load(g0, hi, s2);
+                if (wave == 0 && hi == 0) {  // b = p0 + p1 into the second partial's slots: the first's are W-row ground
+#pragma unroll
+                    for (int a = 0; a < K; ++a) b1[a] = g0[16 * NTP + a] + b1[a];
+                }
+                __syncthreads();  // every wave holds its operands: the W rows go where [G | b] is
+                E16_STAMP(3)
+#ifndef E16_DIAG_NOFACTOR
+                sc.factor(hi, pm, pe);
+#else
+                pm = 1.0; pe = 0;
+#endif
+                E16_STAMP(4)
+                sc.store(lrow, hi, wave);
+            }
+            __syncthreads();
+            E16_STAMP(5)
+#pragma unroll
+            for (int a = 0; a < K; ++a) z[a] = b1[a];
+            static_assert(NF == 4 && (K + 1) / 2 <= 8, "pair w and its mirror 7 - w per wave");
+#ifndef E16_DIAG_NOSOLVES
+            solve_lds<K>(lrow, z, quad, zz);
+            static_for<NF>([&](auto w_tag) {
+                constexpr int w = decltype(w_tag)::value;
+                if (wave == w) {
+                    static_for<2>([&](auto i_tag) {
+                        constexpr int pp = decltype(i_tag)::value == 0 ? first_pair(w) : second_pair(K, w), c0 = 2 * pp;
+                        if constexpr (pp >= 0) {
+                            const double zc = (hi && c0 + 1 < K) ? z[c0 + 1 < K ? c0 + 1 : c0] : z[c0];
+                            // P = z z^T + Sigma, Sigma = sigma^2 M^-1 (ppca_model.rs:437-439), weighted
+                            trpart += minv_pair_lds<K, c0>(lrow, hi, [&](int t, double v) {
+                                const bool ok = t > c0 || hi == 0;
+                                if (ok && c0 + hi < K) wrow[tri(t, c0) + hi] = wgt * (z[t] * zc + s2 * v);
+                            });
+                        }
+                    });
+                }
+            });
+#endif
+            } else {
+                // k <= 13: the packed factor fits a lane's registers (Posterior<K>, ppca_small.hpp) -- every wave factors every
+                // sample (lanes 32-63 mirror 0-31) and the waves share the columns of M^-1, two per instruction stream
+            Posterior<K> post;
             post.load([&](int e) { return g0[e]; }, s2);
 #pragma unroll
             for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a] + b1[a];
@@ -390,7 +685,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __syncthreads();
             post.factor_loaded(pm, pe);
             post.solve_loaded(z, quad, zz);
-            double trpart = 0.0;
 #pragma unroll
             for (int pp = 0; pp < (K + 1) / 2; ++pp) {
                 if (pair_owner(K, pp, NF) != wave) continue;
@@ -401,12 +695,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (ok && c0 + hi < K) wrow[tri(t, c0) + hi] = wgt * (z[t] * zc + s2 * v);
                 });
             }
+            }
+            E16_STAMP(6)
             // tr(C_o Sigma C_o^T) = <Sigma, G> = s2 (K - s2 tr M^-1)  (:345); all-masked samples are filtered out (:333)
             if (m > 0) sc_sq -= wgt * s2 * s2 * trpart;
             if (wave == 0 && hi == 0) {
                 const double run_dev = scl[L_DEV + i], run_llk = scl[L_LLK + i], run_w = scl[L_W + i], run_ne = scl[L_NE + i];
                 const double run_pm = scl[L_PM + i], run_px = scl[L_PX + i];
-                double *zrow = wrow + 16 * NTP;  // W row = [w P (K') | .. | w z (K) | w | ..]
+                double *zrow = wrow + KP;  // W row = [w P (K') | w z (K) | w | ..]: the layout of the hand-over buffer
 #pragma unroll
                 for (int a = 0; a < K; ++a) zrow[a] = wgt * z[a];
                 zrow[K] = wgt;
@@ -434,49 +730,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             scl[wave * SQW + lane] += sc_sq;
         }
         __syncthreads();  // the tile's W rows are final
-        E16_STAMP(1)
+        E16_STAMP(7)
         // ------------------------------------------------------------ P4a: cross += X~^T [wz]; the rows leave for HBM
+        // behind the MFMAs: 16-byte pieces of the compact rows (column c of a row: wP for c < K', then wz, w, zeros)
         {
             double bzb[2], axb[2][RT];
+            p.Mb[tile * 256 + 64 * wave + lane] = Mb[64 * wave + lane];  // (ahead of the row loads: nothing here may wait for them)
             const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile + 1);
-            bzb[0] = Ws[l4 * WS + 16 * NTP + l15];
+            bzb[0] = Ws[l4 * WS + KP + l15];  // (columns past K of the tile: stale values, in output columns nobody stores)
 #pragma unroll
             for (int r = 0; r < RT; ++r) axb[0][r] = Xs[l4 * XS + DW * wave + 16 * r + l15];
+            const int64_t row0 = tile * B;
+            const int valid = (int)(n - row0 < B ? n - row0 : B);
+            double *wout = p.Wrows + row0 * NCOL;
+            constexpr int NCH = B * NCOL / 2, CPT = (NCH + 255) / 256;
+            // the pieces are read up front, unconditionally, one 16-byte LDS read each (8-byte reads at a 16-byte lane
+            // stride are four-way bank conflicts, times four waves: 3.5 k cycles per tile)
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            d2_t pv[CPT];
+            const int ci0 = 64 * wave + lane;  // (from the opaque lane: nothing of this is hoisted out of the tile loop and parked)
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                int ci = ci0 + 256 * u;
+                ci = (NCH % 256 == 0 || ci < NCH) ? ci : NCH - 1;
+                const int r = ci / (NCOL / 2), c = 2 * (ci - r * (NCOL / 2));
+                const d2_t a = *reinterpret_cast<const d2_t *>(Ws + r * WS + c);
+                pv[u] = d2_t{c < NC ? a[0] : 0.0, c + 1 < NC ? a[1] : 0.0};
+            }
+            auto copy_piece = [&](int u) {
+                const int ci = ci0 + 256 * u;
+                const int r = ci / (NCOL / 2);  // (past the tile for the pieces of the last round that do not exist)
+#if E16_STORE_MODE == 1
+                if (r < valid) __builtin_nontemporal_store(pv[u], reinterpret_cast<d2_t *>(wout) + ci);
+#elif E16_STORE_MODE == 2
+                if (r < valid && pv[u][0] == 1.25e-300) reinterpret_cast<d2_t *>(wout)[ci] = pv[u];  // (diagnostic: no stores)
+#else
+                if (r < valid) reinterpret_cast<d2_t *>(wout)[ci] = pv[u];
+#endif
+            };
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
+#ifndef E16_DIAG_NOLOAD
                 if (s < RPW) load_row(trs, s);  // unconditional (rows past the end read as zeros)
+#endif
                 if (s + 1 < 8) {
                     const int smp = 4 * (s + 1) + l4;
-                    bzb[(s + 1) & 1] = Ws[smp * WS + 16 * NTP + l15];
+                    bzb[(s + 1) & 1] = Ws[smp * WS + KP + l15];
 #pragma unroll
                     for (int r = 0; r < RT; ++r) axb[(s + 1) & 1][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s & 1][r], bzb[s & 1], accX[r]);
+#ifndef E16_DIAG_NOCOPY
+#pragma unroll
+                for (int u = s; u < CPT; u += 8) copy_piece(u);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // [wP | wz | w] rows of the tile -> HBM, compact (column c of the row: wP for c < K', then wz, w, zeros)
-            const int64_t row0 = tile * B;
-            const int valid = (int)(n - row0 < B ? n - row0 : B);
-            double *wout = p.Wrows + row0 * NCOL;
-            for (int idx = tid; idx < B * NCOL; idx += 256) {
-                const int r = idx / NCOL, c = idx - r * NCOL;
-                const double v = c < NC ? Ws[r * WS + (c < KP ? c : 16 * NTP + (c - KP))] : 0.0;
-                if (r < valid) wout[idx] = v;
-            }
-            p.Mb[tile * 256 + tid] = Mb[tid];
+#ifdef E16_DIAG_NOLOAD
+#pragma unroll
+            for (int s = 0; s < RPW; ++s) load_row(trs, s);
+#endif
+            E16_STAMP(8)
         }
         __syncthreads();  // the x~ tile, the rows and the sample masks are free
-        E16_STAMP(2)
+        E16_STAMP(9)
         // ------------------------------------------------------------ P1 of the next tile
+        if constexpr (SPLIT) load_cf(lane);
         stage_tile(tile + 1, lane);
         __syncthreads();
-        E16_STAMP(3)
+        E16_STAMP(10)
     }
 #ifdef PPCA_PHASE_TIMING
     if (p.dbg && tid == 0)
-        for (int i = 0; i < 4; ++i) p.dbg[(int64_t)blockIdx.x * 16 + i] = (double)tph[i];
+        for (int i = 0; i < 11; ++i) p.dbg[(int64_t)blockIdx.x * 16 + i] = (double)tph[i];
 #endif
 
     // ---------------------------------------------------------------- epilogue

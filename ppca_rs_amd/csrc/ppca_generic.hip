@@ -13,6 +13,7 @@
 // Chunk results are accumulated in chunk order (deterministic).  Correctness first: the
 // GEMM is a plain LDS-staged 64x64 tile kernel on v_mfma_f64_16x16x4_f64.
 #include <algorithm>
+#include <vector>
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -2078,8 +2079,28 @@ static hipError_t run_em16(const double *X, int64_t ldx, const double *w, int64_
         a.X = Xc; a.ldx = ldx; a.w = w ? w + r0 : nullptr; a.n = nc; a.d = d; a.model = model;
         a.part = W.e16_part; a.qtab = qtab; a.qscale = qscale; a.qflag = qflag; a.Gext = W.G;
         a.Wrows = W.e16_W; a.Mb = W.e16_Mb; a.no_llk = 0; a.dbg = nullptr;
+#ifdef PPCA_PHASE_TIMING
+        double *dbg = nullptr;
+        GTRY(hipMalloc(&dbg, sizeof(double) * 16 * (size_t)grid));
+        GTRY(hipMemsetAsync(dbg, 0, sizeof(double) * 16 * (size_t)grid, s));
+        a.dbg = dbg;
+#endif
         GTRY(launch_em16(k, grid, a, s));
         GTRY(launch_reduce_partials(W.e16_part, grid, L.len, stats, s, r0 > 0 ? 1 : 0));
+#ifdef PPCA_PHASE_TIMING
+        {
+            std::vector<double> h((size_t)grid * 16);
+            GTRY(hipMemcpyAsync(h.data(), dbg, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+            GTRY(hipStreamSynchronize(s));
+            GTRY(hipFree(dbg));
+            double t[16] = {0};
+            for (int g2 = 0; g2 < grid; ++g2)
+                for (int i = 0; i < 16; ++i) t[i] += h[(size_t)g2 * 16 + i] / grid;
+            const double tiles = (double)((nc + 31) / 32) / grid;
+            fprintf(stderr, "[em16 estep cycles/tile] P2: b %.0f  Gram %.0f  stores+barrier %.0f | P3: load+barrier %.0f  factor %.0f  solve %.0f  columns %.0f  scalars+barrier %.0f | P4a cross %.0f  rows->HBM+barrier %.0f | staging+barrier %.0f  (tiles/WG %.1f)\n",
+                    t[0] / tiles, t[1] / tiles, t[2] / tiles, t[3] / tiles, t[4] / tiles, t[5] / tiles, t[6] / tiles, t[7] / tiles, t[8] / tiles, t[9] / tiles, t[10] / tiles, tiles);
+        }
+#endif
     }
     return hipSuccess;
 }
