@@ -398,6 +398,77 @@ def test_fused_path_shape_sweep(P, oracle, k):
             assert _rel(P.Dataset._wrap(h, ds._ctx).numpy(), oracle.covariance_diagonal(x, s, c, mu, name)) < 1e-8
 
 
+@pytest.mark.parametrize("k", list(range(11, 17)))
+def test_two_kernel_em_pass_shape_sweep(P, oracle, k):
+    """State sizes 11..16 at d <= 256 (the reference's own largest workload is d = 200, k = 16: lib.rs:82-99) run the EM
+    pass as the two fused kernels of ppca_em16.hip -- each k its own instantiation (k <= 13: factor in registers, k >= 14:
+    split over lane pairs and parked in LDS): ragged d and N, weights and none, an all-masked row, more than one chunk
+    of the hand-over buffer, statistics buffer against the oracle and two EM iterations end to end."""
+    from ppca_rs_amd import _lib
+
+    rng = np.random.default_rng(140 + k)
+    for d, n in ((256, 97), (255, 64), (200, 33), (64, 129), (k + 3, 31), (200, 700)):
+        assert _lib.lib().ppca_path_kind(d, k) == 0  # (the other passes of these shapes stay on the split pipeline)
+        x, _, _ = oracle.synth(n, d, k, 0.35, 900 + 10 * k + d)
+        x[n // 2] = np.nan
+        w = rng.uniform(0.25, 2.0, n)
+        c, mu, s = 0.5 * rng.standard_normal((d, k)), 0.2 * rng.standard_normal(d), 0.6
+        m = P.PPCAModel(s, c, mu)
+        L = _lib.lib().ppca_stats_len(d, k)
+        got = np.empty(L)
+        kp = k * (k + 1) // 2
+        bounds = [0, d * k, d * k + d * kp, 2 * d * k + d * kp, 2 * d * k + d * kp + d, 2 * d * k + d * kp + 2 * d, L]
+        for weights in (w, None):
+            ds = P.Dataset(x, weights)
+            _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
+            want = oracle.stats(x, s, c, mu, weights)
+            for name, a, b in zip(["cross", "S", "U", "sumx", "totals", "scalars"], bounds[:-1], bounds[1:]):
+                assert _rel(got[a:b], want[a:b]) < 1e-9, (name, d, n, weights is None)
+    ds = P.Dataset(x, w)
+    for _ in range(2):
+        want_llk = oracle.llk(x, s, c, mu, w)
+        s, c, mu = oracle.iterate(x, s, c, mu, w)
+        m, llk = m.iterate_with_llk(ds)
+        assert abs(llk - want_llk) < 1e-9 * abs(want_llk)
+        assert abs(m.isotropic_noise - s) < RTOL * s and _rel(m.transform, c) < RTOL and _rel(m.mean, mu) < RTOL
+
+
+def test_two_kernel_em_pass_chunks_and_guard(P, oracle):
+    """ppca_em16.hip across several chunks of its hand-over buffer (PPCA_GEN_CHUNK, read per call) and on a model that
+    trips the int8 Gram guard (Gram rows from the fp64 product instead): both against the oracle; and the switch back to
+    the split pipeline (PPCA_EM16=0 is read once per process: checked in a child)."""
+    import subprocess, sys
+    from ppca_rs_amd import _lib
+
+    d, k, n = 200, 16, 700
+    rng = np.random.default_rng(3)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 77)
+    w = rng.uniform(0.5, 1.5, n)
+    c, mu, s = 0.3 * rng.standard_normal((d, k)), 0.1 * rng.standard_normal(d), 0.9
+    L = _lib.lib().ppca_stats_len(d, k)
+    want = oracle.stats(x, s, c, mu, w)
+    code = ("import os, sys, numpy as np; sys.path.insert(0, %r); import ppca_rs_amd as P; from ppca_rs_amd import _lib;"
+            "g = np.load(sys.argv[1]); ds, m = P.Dataset(g['x'], g['w']), P.PPCAModel(float(g['s']), g['c'], g['mu']);"
+            "got = np.empty(int(g['L'])); _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)));"
+            "np.save(sys.argv[2], got)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), x=x, w=w, s=s, c=c, mu=mu, L=L)
+        for env in ({"PPCA_GEN_CHUNK": "256"}, {"PPCA_EM16": "0"}):
+            out = os.path.join(td, "out.npy")
+            subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.npz"), out], check=True, env={**os.environ, **env}, timeout=600)
+            assert _rel(np.load(out), want) < 1e-9, env
+    # rows spanning 1e8 and a tiny sigma: both bounds of the guard fail -> fp64 Gram rows (ill-conditioned by construction)
+    c2 = c.copy(); c2[: d // 2] *= 1e-4
+    m2, ds = P.PPCAModel(1e-5, c2, mu), P.Dataset(x, w)
+    eng = C.c_int32(-1)
+    _lib.check(_lib.lib().ppca_gram_engine(ds._ctx.handle, m2._device(ds._ctx).h, C.byref(eng)))
+    assert eng.value == 1
+    got = np.empty(L)
+    _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m2._device(ds._ctx).h, _lib.ptr(got)))
+    assert _rel(got, oracle.stats(x, 1e-5, c2, mu, w)) < 1e-4
+
+
 def test_reference_usage_patterns():
     """The call patterns of the reference's own examples (examples/*.py: keyword construction, np.matrix and
     transposed inputs, row or column means, positional mask probability, the `ppca_rs.ppca_rs` submodule, pickling,
