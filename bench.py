@@ -449,6 +449,9 @@ def main() -> None:
                     kernel_name = f"ppca::pass_kernel<{k}, true, 4, true, false>"
                 else:
                     kernel_name = f"ppca::em8_kernel<{k}, false>"
+            elif d <= 256 and 11 <= k <= 16 and os.environ.get("PPCA_EM16") != "0":
+                kernel_name = (f"ppca::estep16_kernel<{k}> + ppca::sstat16_kernel<{k}> per chunk of 2^20 rows (the two fused kernels of "
+                               "one pass and their partial reduction, timed as one region)")
             else:
                 kernel_name = "generic split pipeline (all kernels of one pass, timed as one region)"
         roofline = {
