@@ -391,6 +391,106 @@ __global__ __launch_bounds__(256) void gen_maskbytes_kernel(const double *X, int
     *reinterpret_cast<gi4_t *>(AT + (int64_t)(j0 + r) * npad + i0 + 16 * q) = u.vv;  // dims up to dpad: zeros beyond d
 }
 
+// Everything the split pipeline needs from X before the per-sample solve, in ONE pass over the chunk's rows (rowstats_kernel,
+// gen_maskbytes_kernel and gemm_kernel<1> read X once each: three of the pipeline's four passes over X, and X is the
+// largest operand of every shape this pipeline serves):
+//   xx_i = sum_obs (x - mu)^2, m_i = #observed          (rowstats_kernel's summation order: lane-strided, then the wave)
+//   mask bytes in both orientations (when want_bytes)    (gen_maskbytes_kernel's tiles)
+//   b = X~ C into Bz[i][0 .. k) (row stride k + 1)       (fp64 MFMA, k <= 16 NT columns)
+// One workgroup per 64 samples, looping over 64-dim blocks: every wave reads its 16 rows as whole 512-byte segments
+// (lane = dim); x~ and the block's rows of C go through LDS to the MFMA (A: this wave's own 16 rows; row stride 68
+// doubles: 8 banks per row, two passes per read, the minimum for 64 doubles).
+template <int NT>
+__global__ __launch_bounds__(256) void gen_prep_kernel(const double *X, int64_t ldx, int64_t n, int d, int dpad, int64_t npad,
+                                                       const double *model, int k, unsigned char *A, unsigned char *AT,
+                                                       double *xx, double *mcount, double *Bz, int want_bytes) {
+    constexpr int CT = NT < 2 ? NT : 2;  // column tiles of C in LDS at a time (static LDS stays under 64 KB)
+    constexpr int XS2 = 68, CS2 = 16 * CT + 1;
+    __shared__ __attribute__((aligned(16))) double xt[64 * XS2];
+    __shared__ __attribute__((aligned(16))) double cs[64 * CS2];
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64][80];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const double *mean = model + MODEL_HDR + (int64_t)d * k;
+    const double *Cm = model + MODEL_HDR;
+    double sxx[16], smc[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) sxx[rr] = smc[rr] = 0.0;
+    d4g_t acc[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt] = d4g_t{0, 0, 0, 0};
+    for (int j0 = 0; j0 < dpad; j0 += 64) {
+        const int j = j0 + lane;
+        const double mu = j < d ? mean[j] : 0.0;
+        double v[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int64_t row = i0 + 16 * wave + rr;
+            v[rr] = (row < n && j < d) ? X[row * ldx + j] : __builtin_nan("");
+        }
+        auto load_c = [&](int h) {  // columns 16 CT h .. of the block's rows of C (zero past d and past k)
+            for (int idx = t; idx < 64 * 16 * CT; idx += 256) {
+                const int jj = idx / (16 * CT), a = 16 * CT * h + idx - jj * (16 * CT);
+                cs[jj * CS2 + (a - 16 * CT * h)] = (j0 + jj < d && a < k) ? Cm[(int64_t)(j0 + jj) * k + a] : 0.0;
+            }
+        };
+        load_c(0);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const bool fin = __builtin_isfinite(v[rr]);
+            const double xv = fin ? v[rr] - mu : 0.0;
+            tile[16 * wave + rr][lane] = fin ? 1 : 0;
+            xt[(16 * wave + rr) * XS2 + lane] = xv;
+            sxx[rr] += xv * xv;
+            smc[rr] += fin ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (want_bytes) {
+            const int r = t >> 2, q = t & 3;
+            union { unsigned char b[16]; gi4_t vv; } u;
+            u.vv = *reinterpret_cast<const gi4_t *>(&tile[r][16 * q]);
+            *reinterpret_cast<gi4_t *>(A + (i0 + r) * dpad + j0 + 16 * q) = u.vv;  // rows up to npad: zeros beyond n
+#pragma unroll
+            for (int e = 0; e < 16; ++e) u.b[e] = tile[16 * q + e][r];
+            *reinterpret_cast<gi4_t *>(AT + (int64_t)(j0 + r) * npad + i0 + 16 * q) = u.vv;  // dims up to dpad: zeros beyond d
+        }
+#pragma unroll
+        for (int h = 0; h < NT / CT; ++h) {
+            if (h > 0) {
+                __syncthreads();
+                load_c(h);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const double a = xt[(16 * wave + l15) * XS2 + 4 * s + l4];
+#pragma unroll
+                for (int tt = 0; tt < CT; ++tt)
+                    acc[CT * h + tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, cs[(4 * s + l4) * CS2 + 16 * tt + l15], acc[CT * h + tt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const double sx = gwave_sum(sxx[rr]), sm = gwave_sum(smc[rr]);
+        const int64_t row = i0 + 16 * wave + rr;
+        if (lane == 0 && row < n) {
+            xx[row] = sx;
+            mcount[row] = sm;
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = i0 + 16 * wave + l4 + 4 * r;
+            const int col = 16 * tt + l15;
+            if (row < n && col < k) Bz[row * (k + 1) + col] = acc[tt][r];
+        }
+}
+
 // smallest non-zero squared row norm of C (guard of the Gram digits); one workgroup
 __global__ __launch_bounds__(256) void gen_rmin_kernel(const double *model, int d, int k, double *rmin_out, int *flags) {
     __shared__ unsigned long long best;
@@ -2031,6 +2131,14 @@ static hipError_t set_solve_lds(int k) {
     } while (0)
 
 // E-step + statistics of all rows into stats (overwritten).  post == true: only the solve outputs.
+// PPCA_GENERIC_PREP=0: rowstats_kernel, gen_maskbytes_kernel and gemm_kernel<1> as three passes over X (A/B runs)
+static bool prep_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_GENERIC_PREP");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
 // PPCA_EM16=0: the split pipeline below also for 11 <= k <= 16, d <= 256 (A/B runs against ppca_em16.hip)
 static bool em16_enabled() {
     static const bool v = [] {
@@ -2133,16 +2241,27 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         const int64_t nc = std::min(W.chunk, n - r0);
         const double *Xc = X + r0 * ldx;
         const double *wc = w ? w + r0 : nullptr;
-        hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, s, Xc, ldx, nc, d, model, k,
-                           W.xx, W.mc);
-        GTRY(hipGetLastError());
         GemmArgs g{};
         g.X = Xc; g.ldx = ldx; g.mean = mean;
         const int64_t ncpad = pad64(nc);
-        if (i8) {
-            dim3 mg((unsigned)(W.dpad / 64), (unsigned)(ncpad / 64));
-            hipLaunchKernelGGL(gen_maskbytes_kernel, mg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, W.A, W.AT);
+        const bool prep = prep_enabled();
+        if (prep) {  // row statistics, mask bytes and b = X~ C in one pass over the chunk's rows
+            const dim3 pg((unsigned)(ncpad / 64));
+            if (k <= 16) hipLaunchKernelGGL((gen_prep_kernel<1>), pg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
+            else if (k <= 32) hipLaunchKernelGGL((gen_prep_kernel<2>), pg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
+            else hipLaunchKernelGGL((gen_prep_kernel<4>), pg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
             GTRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, s, Xc, ldx, nc, d, model, k,
+                               W.xx, W.mc);
+            GTRY(hipGetLastError());
+        }
+        if (i8) {
+            if (!prep) {
+                dim3 mg((unsigned)(W.dpad / 64), (unsigned)(ncpad / 64));
+                hipLaunchKernelGGL(gen_maskbytes_kernel, mg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, W.A, W.AT);
+                GTRY(hipGetLastError());
+            }
             // G = Mask . Q on the int8 MFMA (exact integer accumulation) unless the guard raised flags[0]
             I8GemmArgs q{};
             q.A = W.A; q.lda = W.dpad; q.Bt = W.BtQ; q.ldb = W.dpad; q.plane = kp * (int64_t)W.dpad;
@@ -2156,10 +2275,11 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         g.guard = i8 ? W.flags : nullptr; g.run_if = 1;
         GTRY(launch_gemm<0>(g, s));
         g.guard = nullptr;
-        // b = X~ . C
-        g.B = Cm; g.ldb = k; g.N = k;
-        g.out0 = W.Bz; g.ld0 = k + 1; g.ncols0 = k;
-        GTRY(launch_gemm<1>(g, s));
+        if (!prep) {  // b = X~ . C
+            g.B = Cm; g.ldb = k; g.N = k;
+            g.out0 = W.Bz; g.ld0 = k + 1; g.ncols0 = k;
+            GTRY(launch_gemm<1>(g, s));
+        }
         SolveArgs a{};
         a.G = W.G; a.Bz = W.Bz; a.xx = W.xx; a.mc = W.mc; a.w = wc; a.n = nc; a.k = k;
         a.model = model; a.sc = W.sc; a.em = em ? 1 : 0;

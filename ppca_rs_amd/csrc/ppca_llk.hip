@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
     // One descriptor per tile (base = its first row, extent = its real rows): the row is a scalar offset, the lane
     // a constant VGPR, the half an immediate.  Rows past n read as zeros ("observed", but no lane's sample).
     auto load_tile = [&](int64_t tile) {
+#ifdef LLK2_DIAG_RESIDENT  // measurement only: every tile re-reads the workgroup's first one (L2-resident: the sweep without HBM)
+        const int rel0 = 0;
+#else
         const int rel0 = (int)(tile - tile_begin) * B;
+#endif
         int cnt = nrel - rel0;
         cnt = __builtin_amdgcn_readfirstlane(cnt < 0 ? 0 : (cnt > B ? B : cnt));  // (keeps the descriptor scalar)
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
