@@ -98,6 +98,9 @@ struct S16Args {
 #ifndef E16_STORE_MODE
 #define E16_STORE_MODE 0
 #endif
+#ifndef E16_FACTOR_SWAP
+#define E16_FACTOR_SWAP 0
+#endif
 #ifdef PPCA_PHASE_TIMING
 #define E16_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
 #else
@@ -175,6 +178,71 @@ struct SplitChol {
 #pragma unroll
                     for (int j = jlo; j <= a / 2; ++j) L[idx(a, j)] -= pc[a] * ps[j];
             }
+        });
+        int e0, e1;
+        pm = frexp(grp[0], &e0) * frexp(grp[1], &e1);
+        pe = e0 + e1;
+    }
+    // The same factorisation with the pivot column exchanged through LDS instead of v_permlane32_swap: the owner half
+    // drops the raw column into the wave's exchange slots xch[0 .. K) (a dead stretch of the sample's Gram row), both
+    // halves read it back (one address per lane pair), scale it themselves, and the scaled column -- final -- goes
+    // straight to the factor buffer lrow (wave c mod 4 writes column c: the four waves hold the same values).  A swap
+    // cost two copies and two wait states per word on top of itself (the instruction overwrites both operands), and the
+    // owner's registers had to be refreshed by selects: 2 200 instructions per factorisation against ~1 100 here.
+    __device__ __forceinline__ void factor_lds(int hi, double *xch, double *lrow, int wave, double &pm, int &pe) {
+        double grp[2] = {1.0, 1.0};
+        double raw[2][K];  // the pivot column as read back, current / next step
+        if (hi == 0) {
+#pragma unroll
+            for (int a = 0; a < K; ++a) xch[a] = L[idx(a, 0)];
+        }
+        // (lanes exchange data here: the loads must stay behind the other half's stores -- to a single thread's memory
+        //  model they are independent; the LDS itself serves a wave's operations in order)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < K; ++a) raw[0][a] = xch[a];
+        static_for<K>([&](auto c_tag) {
+            constexpr int c = decltype(c_tag)::value, hc = c & 1, jc = c >> 1;
+            double pc[K];
+            const double piv = raw[c & 1][c];
+            grp[c >= (K + 1) / 2] *= piv;
+            const double inv = fast_rsqrt(piv);  // 1 / L_cc
+#pragma unroll
+            for (int a = c + 1; a < K; ++a) pc[a] = raw[c & 1][a] * inv;
+            if constexpr (c + 1 < K) {
+                constexpr int jlo = hc ? jc + 1 : jc, jhi = (K - 1) / 2;
+                double ps[jhi + 1];
+#pragma unroll
+                for (int j = jlo; j <= jhi; ++j) {
+                    const double v0 = (2 * j > c) ? pc[2 * j] : 0.0;
+                    const double v1 = (2 * j + 1 < K) ? pc[2 * j + 1] : 0.0;
+                    ps[j] = hi ? v1 : v0;
+                }
+                // the next pivot column first (column c + 1 = slot j1 of half h1): it leaves for the exchange slots and
+                // is requested back at once, and the round trip runs under the rest of this step's updates
+                constexpr int c1 = c + 1, h1 = c1 & 1, j1 = c1 >> 1;
+#pragma unroll
+                for (int a = c1; a < K; ++a) L[idx(a, j1)] -= pc[a] * ps[j1];
+                if (hi == h1) {
+#pragma unroll
+                    for (int a = c1; a < K; ++a) xch[a] = L[idx(a, j1)];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int a = c1; a < K; ++a) raw[c1 & 1][a] = xch[a];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = c + 1; a < K; ++a)
+#pragma unroll
+                    for (int j = jlo; j <= a / 2; ++j)
+                        if (j != j1) L[idx(a, j)] -= pc[a] * ps[j];
+            }
+            if ((c & 3) == wave && hi == hc) {  // the scaled column is final: into the factor buffer
+                lrow[tri(c, c)] = inv;
+#pragma unroll
+                for (int a = c + 1; a < K; ++a) lrow[tri(a, c)] = pc[a];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         });
         int e0, e1;
         pm = frexp(grp[0], &e0) * frexp(grp[1], &e1);
@@ -642,13 +710,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 __syncthreads();  // every wave holds its operands: the W rows go where [G | b] is
                 E16_STAMP(3)
-#ifndef E16_DIAG_NOFACTOR
+#if E16_FACTOR_SWAP  // (the exchange by v_permlane32_swap, kept for A/B runs)
                 sc.factor(hi, pm, pe);
-#else
-                pm = 1.0; pe = 0;
-#endif
                 E16_STAMP(4)
                 sc.store(lrow, hi, wave);
+#else
+                sc.factor_lds(hi, Gs + i * GS + 16 * wave, lrow, wave, pm, pe);
+                E16_STAMP(4)
+#endif
             }
             __syncthreads();
             E16_STAMP(5)

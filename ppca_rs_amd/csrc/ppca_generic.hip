@@ -2205,7 +2205,7 @@ static hipError_t run_em16(const double *X, int64_t ldx, const double *w, int64_
             for (int g2 = 0; g2 < grid; ++g2)
                 for (int i = 0; i < 16; ++i) t[i] += h[(size_t)g2 * 16 + i] / grid;
             const double tiles = (double)((nc + 31) / 32) / grid;
-            fprintf(stderr, "[em16 estep cycles/tile] P2: b %.0f  Gram %.0f  stores+barrier %.0f | P3: load+barrier %.0f  factor %.0f  solve %.0f  columns %.0f  scalars+barrier %.0f | P4a cross %.0f  rows->HBM+barrier %.0f | staging+barrier %.0f  (tiles/WG %.1f)\n",
+            fprintf(stderr, "[em16 estep cycles/tile] P2: b %.0f  Gram %.0f  stores+barrier %.0f | P3: load+barrier %.0f  factor %.0f  factor to LDS+barrier %.0f  substitutions %.0f  scalars+barrier %.0f | P4a: cross + rows to HBM %.0f  barrier %.0f | staging (+ C fragments) + barrier %.0f  (tiles/WG %.1f; k <= 13: load .. substitutions are one figure)\n",
                     t[0] / tiles, t[1] / tiles, t[2] / tiles, t[3] / tiles, t[4] / tiles, t[5] / tiles, t[6] / tiles, t[7] / tiles, t[8] / tiles, t[9] / tiles, t[10] / tiles, tiles);
         }
 #endif

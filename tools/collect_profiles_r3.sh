@@ -20,10 +20,15 @@ cp $(first $S/pmc_cfg4_fetch "*counter_collection.csv") $D/pmc_cfg4_FETCH_SIZE_c
 cp $(first $S/pmc_cfg4_write "*counter_collection.csv") $D/pmc_cfg4_WRITE_SIZE_counter_collection.csv
 cp $(first $S/kt_cfg5 "*kernel_stats.csv") $D/bench_cfg5_kernel_stats.csv
 cp $(first $S/kt_d256_k11 "*kernel_stats.csv") $D/cliff_d256_k11_kernel_stats.csv
+cp $(first $S/kt_d200_k16 "*kernel_stats.csv") $D/cliff_d200_k16_kernel_stats.csv
+cp $(first $S/kt_d512_k10 "*kernel_stats.csv") $D/cliff_d512_k10_kernel_stats.csv
 cp $S/passes.log $D/passes_n4m.log
 cp $S/transfer.log $D/transfer.log
 grep "em8 cycles" $S/timing.err | tail -1 > $D/em8_phase_table.log || true
 grep "llk2 cycles" $S/timing_passes.log | tail -1 > $D/llk2_phase_table.log || true
+grep "em16 estep" $S/timing16.err | tail -1 > $D/em16_phase_table.log || true
+grep -v amdgpu $S/llk2_resident.log > $D/llk2_resident.log || true
+grep -v "amdgpu\|cycles" $S/em16_check.log > $D/em16_check.log || true
 mkdir -p $D/cliff
 cp $S/cliff_d*.json $D/cliff/
 python3 - <<PY

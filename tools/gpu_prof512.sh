@@ -1,7 +1,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3p512
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o p -- python3 $GRAFT_REPO_ROOT/bench.py --n 2000000 --d 512 --k 10 --steps 4 --warmup 1 --no-cpu > $OUT/b.json 2> $OUT/b.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o p -- python3 $GRAFT_REPO_ROOT/bench.py --n 2000000 --d ${D:-512} --k ${K:-10} --steps 4 --warmup 1 --no-cpu > $OUT/b.json 2> $OUT/b.err
 python3 - $(find $OUT/p -name "*kernel_stats.csv" | head -1) <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
