@@ -780,23 +780,31 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
         // the only reader of the x~ tile; the next tile's rows are requested one per k-step behind the MFMAs
         {
             load_pair(qbA, 6);  // the next tile's first digit pair (the table does not depend on the tile)
-            double bzb[2], axb[2][RT];
+#ifndef E8_P4A_AHEAD
+#define E8_P4A_AHEAD 1  // k-steps the LDS operands are requested ahead of their MFMAs (measured: 2 and 3 change nothing -- 95.9 / 95.8 / 95.4 it/s -- and cost registers)
+#endif
+            constexpr int AH = E8_P4A_AHEAD, NB3 = AH + 1;
+            double bzb[NB3], axb[NB3][RT];
             const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile + 1);
-            bzb[0] = Ws[l4 * WS + 16 * NTP + l15];
 #pragma unroll
-            for (int r = 0; r < RT; ++r) axb[0][r] = Xs[l4 * XS + DW * wave + 16 * r + l15];
+            for (int s0 = 0; s0 < AH; ++s0) {
+                const int smp = 4 * s0 + l4;
+                bzb[s0] = Ws[smp * WS + 16 * NTP + l15];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) axb[s0][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
+            }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if (s < RPW) load_row(trs, tile + 1, s);  // unconditional (rows past the end read as zeros)
-                if (s + 1 < 8) {
-                    const int smp = 4 * (s + 1) + l4;
-                    bzb[(s + 1) & 1] = Ws[smp * WS + 16 * NTP + l15];
+                if (s + AH < 8) {
+                    const int smp = 4 * (s + AH) + l4;
+                    bzb[(s + AH) % NB3] = Ws[smp * WS + 16 * NTP + l15];
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) axb[(s + 1) & 1][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
+                    for (int r = 0; r < RT; ++r) axb[(s + AH) % NB3][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s & 1][r], bzb[s & 1], accX[r]);
+                for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s % NB3][r], bzb[s % NB3], accX[r]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
