@@ -101,6 +101,9 @@ struct S16Args {
 #ifndef E16_FACTOR_SWAP
 #define E16_FACTOR_SWAP 0
 #endif
+#ifndef E16_CF_EARLY
+#define E16_CF_EARLY 0
+#endif
 #ifdef PPCA_PHASE_TIMING
 #define E16_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
 #else
@@ -535,14 +538,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (and their place in LDS holds the factors): they are requested from L2 behind the previous tile's P4a, arrive
     // during the staging and die with the b product at the head of P2.
     double cf[STEPS];
+    // (one buffer descriptor over C: the lane's offset is one register, the k-step a scalar; dims past d read as zeros,
+    //  lanes past column K are sent out of range)
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(mC), 0, d * K * (int)sizeof(double), 0x00020000);
     auto load_cf = [&](int lane) {
         const int l15 = lane & 15, l4 = lane >> 4, kq = wave >> 1;
+        const int voff = l15 < K ? ((DPS * kq + l4) * K + l15) * 8 : 0x7FFFFFF0;
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
-            const int dim = DPS * kq + l4 + 4 * u;
-            const bool live = dim < d && l15 < K;
-            const double v = mC[live ? dim * K + l15 : 0];
-            cf[u] = live ? v : 0.0;
+            typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+            const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(crsrc, voff, 4 * u * K * 8, 0);
+            cf[u] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
         }
     };
     if (tile_begin < tile_end) {
@@ -805,6 +811,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             double bzb[2], axb[2][RT];
             p.Mb[tile * 256 + 64 * wave + lane] = Mb[64 * wave + lane];  // (ahead of the row loads: nothing here may wait for them)
+#if E16_CF_EARLY
+            if constexpr (SPLIT) load_cf(lane);
+#endif
             const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile + 1);
             bzb[0] = Ws[l4 * WS + KP + l15];  // (columns past K of the tile: stale values, in output columns nobody stores)
 #pragma unroll
@@ -866,7 +875,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();  // the x~ tile, the rows and the sample masks are free
         E16_STAMP(9)
         // ------------------------------------------------------------ P1 of the next tile
+#if !E16_CF_EARLY
         if constexpr (SPLIT) load_cf(lane);
+#endif
         stage_tile(tile + 1, lane);
         __syncthreads();
         E16_STAMP(10)
