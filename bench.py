@@ -442,6 +442,17 @@ def main() -> None:
                 # HBM bytes per sample of the dominant kernel by rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950
                 # correction), measured at the headline size and committed with the commit it was measured on
                 traffic, traffic_src = traffic_from_profiles(rows_local)
+            if (d, k) == (1024, 64):
+                # config 4: HBM bytes per sample and EM step over EVERY kernel of the split pipeline (2 x FETCH_SIZE + WRITE_SIZE
+                # by separate rocprofv3 PMC passes of tools/pmc_generic.py), committed with the commit it was measured on
+                try:
+                    with open(os.path.join(ROOT, "profiles/r03/traffic_cfg4.json")) as fh:
+                        tj = json.load(fh)
+                    traffic = tj["hbm_bytes_per_sample"] * rows_local
+                    traffic_src = (f"profiles/r03/traffic_cfg4.json (commit {tj.get('commit')}, {tj.get('n_samples')} rows x {tj.get('em_steps')} EM steps, "
+                                   "all kernels of one pass; fabric bytes, Infinity-Cache hits included)")
+                except (OSError, KeyError, ValueError):
+                    pass
             if fused:
                 if eng.value == 1:
                     kernel_name = f"ppca::pass_kernel<{k}, true, 4, false, false>"  # the guard's fallback engine
