@@ -1461,14 +1461,19 @@ static hipError_t launch_solve_bc(const SolveArgs &a, int grid, hipStream_t s) {
 // sample of the lane-per-row forms above.  The 16 x 16 diagonal blocks are factored and inverted by the lanes
 // themselves (lane = row, four redundant copies, uniform LDS reads for the shared operands).  Outputs leave through
 // the packed index (coalesced), z = M^-1 b by symmetric row reads.
+constexpr int SOLVE_LDB = 18;
+constexpr int solve_mfma_waves(int nb) { return nb == 4 ? 3 : 4; }
 template <int NB>
-__global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
-    constexpr int N = 16 * NB, LD = N + 2;
+__device__ __forceinline__ void solve_mfma_body(const SolveArgs &a) {
+    // the lower block triangle only, block after block (row stride LD inside a 16 x 16 block): 24 KB per sample at NB = 4
+    // instead of 34, so that two workgroups (of three waves there) share a CU -- two waves per SIMD
+    constexpr int N = 16 * NB, LD = SOLVE_LDB, BSZ = 16 * LD, NBK = NB * (NB + 1) / 2, W = solve_mfma_waves(NB);
     extern __shared__ __attribute__((aligned(16))) double gsm[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    double *Am = gsm + (size_t)wave * (N * LD + 2 * N);
-    double *zs = Am + N * LD;   // z (N)
+    int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int l15 = lane & 15, l4 = lane >> 4;
+    double *Am = gsm + (size_t)wave * (NBK * BSZ + 2 * N);
+    double *zs = Am + NBK * BSZ;   // z (N)
     double *bs = zs + N;        // b (N)
     const int k = a.k, kp = k * (k + 1) / 2;
     const double s2 = a.model[1], lnsig = a.model[2];
@@ -1477,15 +1482,18 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
         const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
         return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
     };
-    auto blk = [&](int i, int j) { return Am + (16 * i) * LD + 16 * j; };
+    auto blk = [&](int i, int j) { return Am + (i * (i + 1) / 2 + j) * BSZ; };  // i >= j
+    auto at = [&](int r, int c) { return blk(r >> 4, c >> 4) + (r & 15) * LD + (c & 15); };  // block row >= block column
     // D = sign * X' Y' + C with X' = X or X^T, Y' = Y or Y^T (16 x 16 blocks in LDS, leading dimension LD)
     auto mma = [&](d4g_t acc, const double *X, bool xT, const double *Y, bool yT, double sign) {
+        __builtin_amdgcn_sched_barrier(0);  // (one block product's operands in flight at a time: the unrolled sweeps hoisted dozens)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const double av = xT ? X[(4 * s + l4) * LD + l15] : X[l15 * LD + 4 * s + l4];
             const double bv = yT ? Y[l15 * LD + 4 * s + l4] : Y[(4 * s + l4) * LD + l15];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * av, bv, acc, 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         return acc;
     };
     auto ldC = [&](const double *Z) {
@@ -1498,8 +1506,14 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Z[(l4 + 4 * r) * LD + l15] = v[r];
     };
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < a.n; i += stride) {
+    if (wave >= W) return;
+    const int64_t stride = (int64_t)gridDim.x * W;
+    for (int64_t i = (int64_t)blockIdx.x * W + wave; i < a.n; i += stride) {
+        // (the lane index goes through an opaque statement per sample: the per-lane LDS addresses of the phases below are then
+        //  recomputed where they are used instead of being hoisted out of the loop and parked -- in scratch at 256 registers)
+        asm volatile("" : "+v"(lane));
+        l15 = lane & 15;
+        l4 = lane >> 4;
         double *g = a.G + i * kp;
         double *bz = a.Bz + i * (k + 1);
         // ---- M into LDS, full symmetric, identity padding; b.  The packed Gram is requested in one burst (NPK loads
@@ -1512,9 +1526,9 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
             gv[q] = g[e < kp ? e : kp - 1];
         }
         if (k < N) {
-            for (int e = lane; e < N * LD; e += 64) Am[e] = 0.0;
+            for (int e = lane; e < NBK * BSZ; e += 64) Am[e] = 0.0;
             for (int e = lane; e < N; e += 64)
-                if (e >= k) Am[e * LD + e] = 1.0;
+                if (e >= k) *at(e, e) = 1.0;
         }
         for (int e = lane; e < N; e += 64) bs[e] = (e < k) ? bz[e] : 0.0;
         {
@@ -1526,8 +1540,8 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
             for (int q = 0; q < NPK; ++q) {
                 if (lane + 64 * q < kp) {
                     const double v = gv[q] + (r == c ? s2 : 0.0);
-                    Am[r * LD + c] = v;
-                    Am[c * LD + r] = v;
+                    *at(r, c) = v;
+                    if ((r >> 4) == (c >> 4)) *at(c, r) = v;  // (diagonal blocks are kept whole: their factorisation reads rows)
                 }
                 c += 64;
                 while (c > r) {
@@ -1543,6 +1557,8 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
         for (int j = 0; j < NB; ++j) {
             double *D = blk(j, j);
             {   // diagonal block: L (lane = row l15), then T = L^-1 (lane = column l15), written back with a zero upper part
+                // (tried: the entries of L by DPP row_newbcast from the owning lane's register instead of uniform LDS reads --
+                //  376 reads per block fewer, but the unrolled broadcasts went to scratch at 256 registers: 306 against 216 ms)
                 double row[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) row[c] = D[l15 * LD + c];
@@ -1618,14 +1634,14 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
             double zacc = 0.0;
             if (r < N) {
                 for (int c = 0; c < N; ++c) {
-                    const double mv = (c <= r) ? Am[r * LD + c] : Am[c * LD + r];
+                    const double mv = (c <= r) ? *at(r, c) : *at(c, r);
                     zacc += mv * bs[c];
                 }
                 zs[r] = zacc;
                 if (r < k) {
                     quad += bs[r] * zacc;
                     zz += zacc * zacc;
-                    tr += Am[r * LD + r];
+                    tr += *at(r, r);
                 }
             }
             zv[q] = zacc;
@@ -1647,7 +1663,7 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
 #pragma unroll
                 for (int q = 0; q < NPK; ++q) {
                     const int e = lane + 64 * q;
-                    if (e < kp) g[e] = wgt * (zs[r] * zs[c] + s2 * Am[r * LD + c]);
+                    if (e < kp) g[e] = wgt * (zs[r] * zs[c] + s2 * *at(r, c));
                     c += 64;
                     while (c > r) {
                         c -= r + 1;
@@ -1670,12 +1686,12 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
                 while ((r + 1) * (r + 2) / 2 <= e) ++r;
                 while (r * (r + 1) / 2 > e) --r;
                 const int c = e - r * (r + 1) / 2;
-                g[e] = s2 * Am[r * LD + c];  // Sigma packed, for the covariance diagonals
+                g[e] = s2 * *at(r, c);  // Sigma packed, for the covariance diagonals
             }
             if (a.covs) {
                 for (int e = lane; e < k * k; e += 64) {
                     const int r = e / k, c = e - r * k;
-                    a.covs[i * (int64_t)k * k + e] = s2 * (c <= r ? Am[r * LD + c] : Am[c * LD + r]);
+                    a.covs[i * (int64_t)k * k + e] = s2 * (c <= r ? *at(r, c) : *at(c, r));
                 }
             }
             if (lane < k) {
@@ -1695,9 +1711,26 @@ __global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
 }
 
 template <int NB>
-static hipError_t launch_solve_mfma(const SolveArgs &a, int grid, hipStream_t s) {
-    constexpr int N = 16 * NB, LD = N + 2;
-    const size_t lds = sizeof(double) * 4 * (N * LD + 2 * N);
+__global__ __launch_bounds__(256) void solve_mfma_kernel(SolveArgs a) {
+    solve_mfma_body<NB>(a);
+}
+// the same capped at 256 registers: two workgroups per CU, two waves per SIMD (the default)
+template <int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void solve_mfma_occ2_kernel(SolveArgs a) {
+    solve_mfma_body<NB>(a);
+}
+
+template <int NB>
+static hipError_t launch_solve_mfma(const SolveArgs &a, int n_cu, hipStream_t s) {
+    constexpr int N = 16 * NB, W = solve_mfma_waves(NB);
+    const size_t lds = sizeof(double) * W * (NB * (NB + 1) / 2 * 16 * SOLVE_LDB + 2 * N);
+    // PPCA_SOLVE_OCC2=0: one workgroup per CU with the whole register file (A/B runs; the form of rounds 2-3)
+    static const bool occ2 = [] {
+        const char *e = getenv("PPCA_SOLVE_OCC2");
+        return !(e && atoi(e) == 0);
+    }();
+    int grid = (int)std::min<int64_t>((a.n + W - 1) / W, (int64_t)n_cu * (occ2 ? 2 : 1));
+    if (grid < 1) grid = 1;
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
@@ -1705,13 +1738,16 @@ static hipError_t launch_solve_mfma(const SolveArgs &a, int grid, hipStream_t s)
     if (lds > 65536 && !(done.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_mfma_kernel<NB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_mfma_occ2_kernel<NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((solve_mfma_kernel<NB>), dim3(grid), dim3(256), lds, s, a);
+    if (occ2) hipLaunchKernelGGL((solve_mfma_occ2_kernel<NB>), dim3(grid), dim3(64 * W), lds, s, a);
+    else hipLaunchKernelGGL((solve_mfma_kernel<NB>), dim3(grid), dim3(64 * W), lds, s, a);
     return hipGetLastError();
 }
-
 static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
     int grid = (int)std::min<int64_t>((a.n + 3) / 4, (int64_t)n_cu);
     if (grid < 1) grid = 1;
@@ -1739,10 +1775,10 @@ static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
         }
     }
     if (!reg && form == 0) {
-        if (a.k <= 16) return launch_solve_mfma<1>(a, grid, s);
-        if (a.k <= 32) return launch_solve_mfma<2>(a, grid, s);
-        if (a.k <= 48) return launch_solve_mfma<3>(a, grid, s);
-        return launch_solve_mfma<4>(a, grid, s);
+        if (a.k <= 16) return launch_solve_mfma<1>(a, n_cu, s);
+        if (a.k <= 32) return launch_solve_mfma<2>(a, n_cu, s);
+        if (a.k <= 48) return launch_solve_mfma<3>(a, n_cu, s);
+        return launch_solve_mfma<4>(a, n_cu, s);
     }
     if (!reg) {
         if (a.k <= 16) return launch_solve_bc<16>(a, grid, s);
