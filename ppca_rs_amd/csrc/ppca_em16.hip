@@ -95,14 +95,8 @@ struct S16Args {
     double *part;          // [grid][stats_len]: this kernel writes S, U, totals
 };
 
-#ifndef E16_STORE_MODE
-#define E16_STORE_MODE 0
-#endif
 #ifndef E16_FACTOR_SWAP
 #define E16_FACTOR_SWAP 0
-#endif
-#ifndef E16_CF_EARLY
-#define E16_CF_EARLY 0
 #endif
 #ifdef PPCA_PHASE_TIMING
 #define E16_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
@@ -526,13 +520,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int q = 0; q < 4; ++q) mbb[(128 * (q >> 1) + 2 * lane + (q & 1)) * 4 + wave] = (unsigned char)st_mb[q];
     };
 
-    // Every workgroup does the same work per tile, so the chip's memory requests would come in bursts: the row loads
-    // (64 KB) and row stores (40 KB) of all 256 workgroups inside the same ~3 k cycles of a ~50 k-cycle tile period
-    // (measured: 7.4 k cycles for a 2.5 k-cycle phase).  A quarter-period start offset per workgroup spreads them.
-#ifndef E16_STAGGER
-#define E16_STAGGER 2
-#endif
-    for (int q = 0; q < (int)(blockIdx.x & 3) * E16_STAGGER; ++q) __builtin_amdgcn_s_sleep(96);
+    // (tried: a quarter-tile-period start offset per workgroup against bursts of the chip's memory requests -- every
+    //  workgroup does the same work per tile -- : no effect, the stall it was aimed at was a scratch reload's vmcnt(0))
     // B operand of b = X~ C: this wave's K-half of C (dims DPS kq + l4 + 4 u, column l15; zeros past d and past K).  The
     // fragments do not depend on the tile, but as kernel-long register residents they were what the factorisation spilled
     // (and their place in LDS holds the factors): they are requested from L2 behind the previous tile's P4a, arrive
@@ -730,7 +719,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int a = 0; a < K; ++a) z[a] = b1[a];
             static_assert(NF == 4 && (K + 1) / 2 <= 8, "pair w and its mirror 7 - w per wave");
-#ifndef E16_DIAG_NOSOLVES
             solve_lds<K>(lrow, z, quad, zz);
             static_for<NF>([&](auto w_tag) {
                 constexpr int w = decltype(w_tag)::value;
@@ -748,7 +736,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     });
                 }
             });
-#endif
             } else {
                 // k <= 13: the packed factor fits a lane's registers (Posterior<K>, ppca_small.hpp) -- every wave factors every
                 // sample (lanes 32-63 mirror 0-31) and the waves share the columns of M^-1, two per instruction stream
@@ -811,9 +798,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             double bzb[2], axb[2][RT];
             p.Mb[tile * 256 + 64 * wave + lane] = Mb[64 * wave + lane];  // (ahead of the row loads: nothing here may wait for them)
-#if E16_CF_EARLY
-            if constexpr (SPLIT) load_cf(lane);
-#endif
             const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile + 1);
             bzb[0] = Ws[l4 * WS + KP + l15];  // (columns past K of the tile: stale values, in output columns nobody stores)
 #pragma unroll
@@ -838,19 +822,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             auto copy_piece = [&](int u) {
                 const int ci = ci0 + 256 * u;
                 const int r = ci / (NCOL / 2);  // (past the tile for the pieces of the last round that do not exist)
-#if E16_STORE_MODE == 1
-                if (r < valid) __builtin_nontemporal_store(pv[u], reinterpret_cast<d2_t *>(wout) + ci);
-#elif E16_STORE_MODE == 2
-                if (r < valid && pv[u][0] == 1.25e-300) reinterpret_cast<d2_t *>(wout)[ci] = pv[u];  // (diagnostic: no stores)
-#else
-                if (r < valid) reinterpret_cast<d2_t *>(wout)[ci] = pv[u];
-#endif
+                if (r < valid) reinterpret_cast<d2_t *>(wout)[ci] = pv[u];  // (non-temporal stores: no difference)
             };
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-#ifndef E16_DIAG_NOLOAD
                 if (s < RPW) load_row(trs, s);  // unconditional (rows past the end read as zeros)
-#endif
                 if (s + 1 < 8) {
                     const int smp = 4 * (s + 1) + l4;
                     bzb[(s + 1) & 1] = Ws[smp * WS + KP + l15];
@@ -860,24 +836,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s & 1][r], bzb[s & 1], accX[r]);
-#ifndef E16_DIAG_NOCOPY
 #pragma unroll
                 for (int u = s; u < CPT; u += 8) copy_piece(u);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-#ifdef E16_DIAG_NOLOAD
-#pragma unroll
-            for (int s = 0; s < RPW; ++s) load_row(trs, s);
-#endif
             E16_STAMP(8)
         }
         __syncthreads();  // the x~ tile, the rows and the sample masks are free
         E16_STAMP(9)
         // ------------------------------------------------------------ P1 of the next tile
-#if !E16_CF_EARLY
         if constexpr (SPLIT) load_cf(lane);
-#endif
         stage_tile(tile + 1, lane);
         __syncthreads();
         E16_STAMP(10)
