@@ -4,7 +4,8 @@
 //   estep16_kernel<K>   one sweep over X: staging (centring, masks), [G | b] (int8-sliced Gram + fp64-MFMA b = X~ C),
 //                       the per-sample k x k solve, the x~-side statistics cross / sumx, the scalars and the llk --
 //                       the front role of em8_kernel (ppca_em8.hip) as its own four-wave workgroup with the whole
-//                       512-entry register file per wave (the packed Cholesky factor alone is 272 registers at k = 16);
+//                       512-entry register file per wave; from k = 14 the packed Cholesky factor (210+ registers) is split
+//                       over lane pairs and parked in LDS for the substitutions (SplitChol, solve_lds, minv_pair_lds);
 //                       writes each sample's row [wP (k') | wz (k) | w] (fp64) and the tile's per-dimension sample masks
 //   sstat16_kernel<K>   S / U / totals (256 x (k' + k + 1)) += Mask^T [wP | wz | w] on the INT8 MFMA with exact 64-bit
 //                       integer accumulation: the back role of em8_kernel as its own eight-wave workgroup (each wave owns
@@ -14,7 +15,8 @@
 // four-wave back role, and the digit planes of a 64-sample group (71 KB) do not fit beside the x~ tile, C and [G | b] in
 // the 160 KB of LDS.  Through HBM the hand-over costs 1 280 B written + read per sample next to the 2 048 B of the row of
 // X itself; each kernel then has the whole CU.  Before this kernel the shapes ran on the split pipeline of
-// ppca_generic.hip (ten launches per chunk, X read four times): 14.5 ms per iteration at d = 200, k = 16, N = 2 M.
+// ppca_generic.hip (ten launches per chunk, X read four times): 14.5 ms per iteration at d = 200, k = 16, N = 2 M;
+// here 6.7 ms (profiles/r03/cliff.md).
 //
 // Fixed-point form, violation handling and flush cadence of the contraction: exactly as in ppca_em8.hip (one exponent
 // per column and workgroup, set by the first tile + 6 binary orders of head room; a tile that does not fit flushes the
