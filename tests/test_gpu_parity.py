@@ -1044,6 +1044,51 @@ def test_full_size_properties_config4(P):
     assert np.isfinite(ex).all()
 
 
+def test_full_size_properties_reference_largest_workload(P):
+    """The reference's own largest workload shape (lib.rs:82-99: d = 200, k = 16) at N = 2.5 M (three chunks of the
+    two-kernel pass, ppca_em16.hip): size-independent properties -- EM monotonicity; the integer path of the
+    statistics kernel BIT-EXACT (totals = per-dimension observed counts, which a column scan of the data gives
+    independently); sumx against a float64 column sum; shard additivity; run-to-run bit reproducibility."""
+    from ppca_rs_amd import _lib
+
+    n, d, k = 2_500_000, 200, 16
+    ctx = _lib.default_context()
+    truth = P.PPCAModel(0.1, np.random.default_rng(1).standard_normal((d, k)), np.random.default_rng(2).standard_normal(d))
+    spec = _lib.SynthSpec(0, n, d, k, 0.1, 0.3, 0, 0, 1033, truth._c.ctypes.data_as(_lib.c_double_p),
+                          truth._mean.ctypes.data_as(_lib.c_double_p))
+    h = C.c_void_p()
+    _lib.check(_lib.lib().ppca_dataset_generate(ctx.handle, C.byref(spec), C.byref(h)))
+    ds = P.Dataset._wrap(h, ctx)
+    m = P.PPCAModel.init(k, ds, seed=3)
+    prev = -np.inf
+    for _ in range(3):
+        m, llk = m.iterate_with_llk(ds)
+        assert np.isfinite(llk) and llk >= prev
+        prev = llk
+    L = _lib.lib().ppca_stats_len(d, k)
+    kp = k * (k + 1) // 2
+    o_sumx, o_tot = 2 * d * k + d * kp, 2 * d * k + d * kp + d
+    dev = m._device(ctx)
+    full, again = np.empty(L), np.empty(L)
+    _lib.check(_lib.lib().ppca_stats_raw(ctx.handle, ds._h, dev.h, _lib.ptr(full)))
+    _lib.check(_lib.lib().ppca_stats_raw(ctx.handle, ds._h, dev.h, _lib.ptr(again)))
+    np.testing.assert_array_equal(full, again)
+    counts, sums = np.zeros(d), np.zeros(d)
+    for ch in ds.chunks(10):  # (250 000 x 200 doubles per download)
+        x = ch.numpy()
+        ob = np.isfinite(x)
+        counts += ob.sum(axis=0)
+        sums += np.where(ob, x - m.mean, 0.0).sum(axis=0)
+    np.testing.assert_array_equal(full[o_tot:o_tot + d], counts)  # exact: sums of 0/1 x weight 1 through int64
+    assert _rel(full[o_sumx:o_sumx + d], sums) < 1e-10
+    acc = np.zeros(L)
+    for ch in ds.chunks(3):
+        part = np.empty(L)
+        _lib.check(_lib.lib().ppca_stats_raw(ctx.handle, ch._h, dev.h, _lib.ptr(part)))
+        acc += part
+    assert _rel(acc, full) < 1e-10
+
+
 def test_full_size_properties_config5(P):
     """BASELINE config 5 at full size on one GPU (8 components, N = 5M, d = 256, k = 10, 30 % masked): the mixture
     log-likelihood never decreases over EM iterations (mix.rs:281-337 is an EM step), the weights stay normalised,
