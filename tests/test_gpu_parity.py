@@ -433,6 +433,31 @@ def test_two_kernel_em_pass_shape_sweep(P, oracle, k):
         assert abs(m.isotropic_noise - s) < RTOL * s and _rel(m.transform, c) < RTOL and _rel(m.mean, mu) < RTOL
 
 
+@pytest.mark.parametrize("k", [12, 16])
+def test_two_kernel_em_pass_rescales_its_fixed_point_form(P, oracle, k):
+    """sstat16_kernel cuts the rows [wP | wz | w] against per-column exponents set by the first tile; weights growing by
+    2^80 over the rows force the cold path again and again (a tile that does not fit: flush the int64 accumulators into
+    the partial, raise the exponents, cut again), descending weights leave the exponents where the first tile put
+    them (precision is then relative to the LARGEST terms, as in any fp64 sum): both against the oracle."""
+    from ppca_rs_amd import _lib
+
+    d, n = 64, 4000
+    rng = np.random.default_rng(7 + k)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 321 + k)
+    c, mu, s = 0.4 * rng.standard_normal((d, k)), 0.1 * rng.standard_normal(d), 0.8
+    m = P.PPCAModel(s, c, mu)
+    L = _lib.lib().ppca_stats_len(d, k)
+    kp = k * (k + 1) // 2
+    bounds = [0, d * k, d * k + d * kp, 2 * d * k + d * kp, 2 * d * k + d * kp + d, 2 * d * k + d * kp + 2 * d, L]
+    for w in (2.0 ** np.linspace(-40, 40, n), 2.0 ** np.linspace(40, -40, n)):
+        ds = P.Dataset(x, w)
+        got = np.empty(L)
+        _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
+        want = oracle.stats(x, s, c, mu, w)
+        for name, a, b in zip(["cross", "S", "U", "sumx", "totals", "scalars"], bounds[:-1], bounds[1:]):
+            assert _rel(got[a:b], want[a:b]) < 1e-9, (name, k, w[0] < w[-1])
+
+
 def test_two_kernel_em_pass_chunks_and_guard(P, oracle):
     """ppca_em16.hip across several chunks of its hand-over buffer (PPCA_GEN_CHUNK, read per call) and on a model that
     trips the int8 Gram guard (Gram rows from the fp64 product instead): both against the oracle; and the switch back to
