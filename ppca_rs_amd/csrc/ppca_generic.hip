@@ -1866,6 +1866,62 @@ __global__ void recon_kernel(const double *X, int64_t ldx, int64_t n, int d, int
     out[idx] = o;
 }
 
+// The same outputs with the work laid out for the machine (round 3, late; recon_kernel above is kept for A/B runs,
+// PPCA_GENERIC_RECON=naive): a thread owns one DIMENSION (its row of C in registers, zero-padded to KPAD columns) and
+// walks the samples of its block; everything per sample -- the state z, the packed Sigma -- is wave-uniform and comes
+// through scalar loads, so an element costs its multiply-adds and one coalesced store (plus the load of x where the
+// mode looks at it: smooth does not).  The naive kernel re-read C, z and Sigma per ELEMENT and divided a 64-bit index:
+// 14 ms for 2 M x 200 at k = 16 where the output is 1.6 ms of HBM; its covariance diagonal -- k^2 indexed loads of
+// Sigma per element -- 227 ms.
+template <int KPAD>
+__global__ __launch_bounds__(256) void recon2_kernel(const double *__restrict__ X, int64_t ldx, int64_t n, int d, int k,
+                                                     const double *__restrict__ model, const double *__restrict__ Bz,
+                                                     const double *__restrict__ G, int mode, double *__restrict__ out,
+                                                     int rows_per_block) {
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    const bool jv = j < d;
+    double c[KPAD];
+#pragma unroll
+    for (int a = 0; a < KPAD; ++a) c[a] = (jv && a < k) ? model[MODEL_HDR + (int64_t)j * k + a] : 0.0;
+    const double mean = jv ? model[MODEL_HDR + (int64_t)d * k + j] : 0.0;
+    const double s2 = model[1];
+    const int kp = k * (k + 1) / 2;
+    const int64_t i0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t i1 = i0 + rows_per_block < n ? i0 + rows_per_block : n;
+    for (int64_t i = i0; i < i1; ++i) {
+        double o;
+        if (mode <= 1) {
+            const double *z = Bz + i * (k + 1);
+            double sacc = mean;
+#pragma unroll
+            for (int a = 0; a < KPAD; ++a) {
+                const double za = a < k ? z[a] : 0.0;  // (uniform: a scalar load and select)
+                sacc += c[a] * za;
+            }
+            o = sacc;
+        } else {
+            const double *sg = G + i * (int64_t)kp;
+            double v = 0.0;
+#pragma unroll
+            for (int a = 0; a < KPAD; ++a) {
+                if (a < k) {  // (uniform)
+                    double t = 0.0;
+#pragma unroll
+                    for (int b = 0; b < a; ++b) t += sg[a * (a + 1) / 2 + b] * c[b];
+                    v += c[a] * (sg[a * (a + 1) / 2 + a] * c[a] + 2.0 * t);
+                }
+            }
+            o = v + s2;
+        }
+        if (mode == 1 || mode == 3) {
+            const double x = jv ? X[i * ldx + j] : 0.0;
+            const bool obs = __builtin_isfinite(x);
+            if (obs) o = (mode == 1) ? x : 0.0;
+        }
+        if (jv) out[i * d + j] = o;
+    }
+}
+
 // ------------------------------------------------------------------ finalisation (runtime k)
 // One wave per dimension: S_j (+ tau I) c = cross_j by Cholesky in LDS; old row kept if not SPD.
 __global__ __launch_bounds__(128) void gen_rowsolve_kernel(const double *stats, const double *min, double *mout, int d,
@@ -2392,9 +2448,22 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
                 GTRY(launch_gemm<3>(g, s, n_cu, W.part, W.part_cap));
             }
         } else if (recon) {
-            const int64_t tot = nc * d;
-            hipLaunchKernelGGL(recon_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, ldx, nc, d, k,
-                               model, W.Bz, W.G, recon_mode, recon + r0 * d);
+            static const bool naive = [] {  // PPCA_GENERIC_RECON=naive: one thread per output element (A/B runs)
+                const char *e = getenv("PPCA_GENERIC_RECON");
+                return e && e[0] == 'n';
+            }();
+            if (naive) {
+                const int64_t tot = nc * d;
+                hipLaunchKernelGGL(recon_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, ldx, nc, d, k,
+                                   model, W.Bz, W.G, recon_mode, recon + r0 * d);
+            } else {
+                // rows per block: enough blocks to fill the chip a few times over, at least 16 rows to amortise the row of C
+                int rpb = (int)std::max<int64_t>(16, std::min<int64_t>(256, nc / (8 * (int64_t)n_cu) + 1));
+                const dim3 rg((unsigned)((nc + rpb - 1) / rpb), (unsigned)((d + 255) / 256));
+                if (k <= 16) hipLaunchKernelGGL((recon2_kernel<16>), rg, dim3(256), 0, s, Xc, ldx, nc, d, k, model, W.Bz, W.G, recon_mode, recon + r0 * d, rpb);
+                else if (k <= 32) hipLaunchKernelGGL((recon2_kernel<32>), rg, dim3(256), 0, s, Xc, ldx, nc, d, k, model, W.Bz, W.G, recon_mode, recon + r0 * d, rpb);
+                else hipLaunchKernelGGL((recon2_kernel<64>), rg, dim3(256), 0, s, Xc, ldx, nc, d, k, model, W.Bz, W.G, recon_mode, recon + r0 * d, rpb);
+            }
             GTRY(hipGetLastError());
         }
     }
