@@ -965,6 +965,8 @@ struct SolveArgs {
     double *llks;     // post (nullable): per-sample llk
     double *states;   // post (nullable): [n][k]
     double *covs;     // post (nullable): [n][k][k]
+    int need_sigma;   // post: some consumer reads the packed Sigma the solver leaves in G (covariances, their diagonals);
+                      // 0: the lane-per-sample solver skips the k inverse columns (llk, states, smooth, extrapolate)
 };
 
 __global__ __launch_bounds__(128) void solve_kernel(SolveArgs a) {
@@ -1076,6 +1078,7 @@ __device__ __forceinline__ void solve_lane_body(const SolveArgs &a) {
                 bz[c] = z[c];  // unweighted state for the reconstruction pass
                 if (a.states) a.states[i * K + c] = z[c];
             }
+            if (a.need_sigma) {
 #pragma unroll
             for (int c = 0; c < K; ++c)
                 (void)post.minv_column(c, [&](int r, int cc, double v) {
@@ -1086,6 +1089,7 @@ __device__ __forceinline__ void solve_lane_body(const SolveArgs &a) {
                         a.covs[(i * K + cc) * K + r] = sv;
                     }
                 });
+            }
             sc[0] = 0.0;
             sc[1] = 0.0;
             sc[2] = wgt * lk;
@@ -2378,6 +2382,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         a.llks = llks ? llks + r0 : nullptr;
         a.states = states ? states + r0 * k : nullptr;
         a.covs = covs ? covs + r0 * (int64_t)k * k : nullptr;
+        a.need_sigma = (covs || (recon && recon_mode >= 2)) ? 1 : 0;
         if (getenv("PPCA_GENERIC_LDS_SOLVE")) {  // the LDS-resident variant, kept for A/B runs
             int sgrid = (int)std::min<int64_t>((nc + 1) / 2, (int64_t)n_cu);
             if (sgrid < 1) sgrid = 1;
