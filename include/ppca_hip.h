@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPCA_ABI_VERSION 3
+#define PPCA_ABI_VERSION 4
 
 typedef enum ppca_status {
     PPCA_OK = 0,
@@ -296,6 +296,18 @@ int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *mod
                          int32_t n_models, int32_t mode, ppca_dataset **out);
 
 /* ------------------------------------------------------------------ debug */
+/* Test hook: cap the number of workgroups of every persistent-grid launch of this context (the fused kernels start
+ * min(tiles, CUs) workgroups, each walking a contiguous run of 32-sample tiles) so that a dataset small enough for the CPU
+ * oracle still gives every workgroup hundreds of tiles -- the steady state of the kernels (tile rings, software
+ * pipelines, the periodic flush of the integer accumulators) under the oracle.  n_workgroups <= 0 restores the device's
+ * CU count.  Results do not depend on the grid beyond the order of the partial sums. */
+int ppca_ctx_set_grid_limit(ppca_ctx *ctx, int32_t n_workgroups);
+/* Diagnostic counters of the int8 statistics contraction of the EM pass on this context's device since the last reset:
+ * out8[0..3] the eight-wave kernel (k <= 10), out8[4..7] the two-kernel pass (k = 11..16): [0] tiles cut again after the
+ * fixed-point exponents were raised (beyond each workgroup's first tile), [1] periodic flushes of the int64
+ * accumulators, [2] the largest number of tiles one workgroup walked, [3] launches.  Synchronises. */
+int ppca_debug_counters(ppca_ctx *ctx, int64_t *out8, int32_t reset);
+
 /* Which Gram engine the fused passes use for this model: 0 = int8-sliced MFMA with exact integer accumulation,
  * 1 = fp64 MFMA.  Decided on the device per model by a dynamic-range guard (the int8 form keeps 54 bits below each
  * column maximum of vech(c c^T); a model whose rows of C span many orders of magnitude, or whose sigma^2 lies

@@ -118,6 +118,8 @@ SIGNATURES = {
     "ppca_em_step_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Prior), C.c_void_p, c_double_p]),
     "ppca_mix_em_step_sharded": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, C.POINTER(Prior), c_void_pp, C.c_void_p, c_double_p]),
     "ppca_em_step_group": (C.c_int, [c_void_pp, C.c_int32, c_void_pp, c_void_pp, C.POINTER(Prior), c_void_pp, c_double_p]),
+    "ppca_ctx_set_grid_limit": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ppca_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "ppca_gram_engine": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p]),
     "ppca_debug_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppca_debug_mfma_i8_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -207,6 +209,16 @@ class Context:
         got = C.c_int64(0)
         check(lib().ppca_ctx_trim(self.handle, C.byref(got)))
         return int(got.value)
+
+    def set_grid_limit(self, n_workgroups: int = 0) -> None:
+        """Test hook (ppca_ctx_set_grid_limit): cap the workgroups of every persistent-grid launch; 0 restores."""
+        check(lib().ppca_ctx_set_grid_limit(self.handle, int(n_workgroups)))
+
+    def debug_counters(self, reset: bool = True):
+        """ppca_debug_counters: 8 counters of the EM pass's int8 statistics contraction (see include/ppca_hip.h)."""
+        out = (C.c_int64 * 8)()
+        check(lib().ppca_debug_counters(self.handle, out, int(reset)))
+        return [int(v) for v in out]
 
     def enable_timing(self, on: bool) -> None:
         check(lib().ppca_ctx_enable_timing(self.handle, int(on)))

@@ -305,6 +305,7 @@ extern "C" int ppca_ctx_create(int32_t device_id, void *stream, ppca_ctx **out) 
     ctx->device = dev;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    ctx->n_cu_device = ctx->n_cu;
     if (stream) {
         ctx->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -1438,6 +1439,25 @@ extern "C" int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model 
 }
 
 // ------------------------------------------------------------------ debug
+// Every launcher sizes its grid from ctx->n_cu (persistent workgroups, one per CU): capping it makes a workgroup walk many
+// tiles at a size the CPU oracle still finishes in seconds.
+extern "C" int ppca_ctx_set_grid_limit(ppca_ctx *ctx, int32_t n_workgroups) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "null context");
+    USE_CTX(ctx);
+    ctx->n_cu = (n_workgroups > 0 && n_workgroups < ctx->n_cu_device) ? n_workgroups : ctx->n_cu_device;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_debug_counters(ppca_ctx *ctx, int64_t *out8, int32_t reset) {
+    if (!ctx || !out8) return fail(PPCA_ERR_INVALID, "null argument");
+    USE_CTX(ctx);
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(em8_debug_counters(c, reset, ctx->stream));
+    HIP_TRY(em16_debug_counters(c + 4, reset, ctx->stream));
+    for (int i = 0; i < 8; ++i) out8[i] = (int64_t)c[i];
+    return PPCA_OK;
+}
+
 extern "C" int ppca_gram_engine(ppca_ctx *ctx, const ppca_model *model, int32_t *engine) {
     if (!ctx || !model || !engine) return fail(PPCA_ERR_INVALID, "null argument");
     if (int rc = check_path(model->d, model->k)) return rc;

@@ -908,6 +908,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ===================================================================== mask-side statistics
+// Diagnostic counters as in ppca_em8.hip: [0] rescales beyond a workgroup's first, [1] periodic flushes, [2] the largest
+// number of tiles one workgroup walked, [3] launches.
+__device__ unsigned long long e16_counters[4];
+
 template <int K>
 __global__ __launch_bounds__(512) void sstat16_kernel(S16Args p) {
     using cfg = Cfg16<K>;
@@ -948,6 +952,7 @@ __global__ __launch_bounds__(512) void sstat16_kernel(S16Args p) {
             for (int q = 0; q < 4; ++q) accM[r][t][q] = 0ll;
     unsigned attempt = 0u;
     int pending = 0, have_scale = 0, flushed = 0, groups = 0;
+    int n_rescale = 0, n_flush = 0;  // (wave-uniform: diagnostic counters)
     StatsLayout L(d, K);
     double *out = p.part + (int64_t)blockIdx.x * L.len;
 
@@ -1177,8 +1182,10 @@ __global__ __launch_bounds__(512) void sstat16_kernel(S16Args p) {
                 emit(lane, flushed != 0, true);
                 flushed = 1;
                 groups = 0;
+                n_flush += viol ? 0 : 1;
             }
             if (!viol) break;
+            n_rescale += have_scale;
             __syncthreads();  // every wave has read the old exponents
             rescale(lane, rows);
             have_scale = 1;
@@ -1188,6 +1195,25 @@ __global__ __launch_bounds__(512) void sstat16_kernel(S16Args p) {
         __syncthreads();
     }
     emit(lane_entry, flushed != 0, false);
+    if (tid == 0) {
+        if (n_rescale) atomicAdd(&e16_counters[0], (unsigned long long)n_rescale);
+        if (n_flush) atomicAdd(&e16_counters[1], (unsigned long long)n_flush);
+        atomicMax(&e16_counters[2], (unsigned long long)(tile_end > tile_begin ? tile_end - tile_begin : 0));
+        if (blockIdx.x == 0) atomicAdd(&e16_counters[3], 1ull);
+    }
+}
+
+hipError_t em16_debug_counters(unsigned long long *out4, int reset, hipStream_t s) {
+    if (hipError_t e = hipMemcpyFromSymbolAsync(out4, HIP_SYMBOL(e16_counters), sizeof(unsigned long long) * 4, 0, hipMemcpyDeviceToHost, s);
+        e != hipSuccess)
+        return e;
+    if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess) return e;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(e16_counters), z, sizeof(z), 0, hipMemcpyHostToDevice, s); e != hipSuccess) return e;
+        return hipStreamSynchronize(s);
+    }
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------ launchers

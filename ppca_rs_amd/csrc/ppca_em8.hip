@@ -61,6 +61,11 @@ constexpr int E8_FLUSH_GROUPS = 100;
 #define E8_FRONT_PRIO 0
 #endif
 
+// Diagnostic counters of the back role (tests prove with them that the cold path and the periodic flush ran): [0] tiles cut
+// again after a rescale of the fixed-point exponents (beyond a workgroup's first), [1] periodic flushes of the int64
+// accumulators, [2] the largest number of tiles one workgroup walked, [3] launches.  One atomic each per workgroup.
+__device__ unsigned long long e8_counters[4];
+
 template <int K>
 struct Cfg8 {
     using c = Cfg<K>;
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
         unsigned attempt = 0u;   // digitise attempts so far (the violation stamp of the current one)
         int pending = 0;         // 1: the previous tile's planes wait in P0 for their partner
         int have_scale = 0, flushed = 0, groups = 0;
+        int n_rescale = 0, n_flush = 0;  // (wave-uniform: diagnostic counters)
         unsigned char *smb = reinterpret_cast<unsigned char *>(sm);
         constexpr int P0_BYTES = cfg::OFF_P0 * 8, PG_BYTES = cfg::OFF_P1 * 8;
         StatsLayout L(d, K);
@@ -435,8 +441,10 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                     emit(lane, flushed != 0, true);
                     flushed = 1;
                     groups = 0;
+                    n_flush += viol ? 0 : 1;
                 }
                 if (!viol) break;
+                n_rescale += have_scale;
                 role_barrier(bbar, bbar_target, lane_entry);  // every wave has read the old exponents
                 rescale(lane);
                 have_scale = 1;
@@ -445,6 +453,12 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             E8_STAMP(7)
         }
         emit(lane_entry, flushed != 0, false);
+        if (tid == 256) {
+            if (n_rescale) atomicAdd(&e8_counters[0], (unsigned long long)n_rescale);
+            if (n_flush) atomicAdd(&e8_counters[1], (unsigned long long)n_flush);
+            atomicMax(&e8_counters[2], (unsigned long long)(tile_end > tile_begin ? tile_end - tile_begin : 0));
+            if (blockIdx.x == 0) atomicAdd(&e8_counters[3], 1ull);
+        }
 #ifdef PPCA_PHASE_TIMING
         if (p.dbg && tid == 256)
             for (int i = 5; i < 8; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
@@ -883,6 +897,19 @@ static hipError_t launch_em8_t(int grid, const PassArgs &a, hipStream_t s) {
     }
     hipLaunchKernelGGL((em8_kernel<K, GATHER, WEIGHTED>), dim3(grid), dim3(512), lds, s, a);
     return hipGetLastError();
+}
+
+hipError_t em8_debug_counters(unsigned long long *out4, int reset, hipStream_t s) {
+    if (hipError_t e = hipMemcpyFromSymbolAsync(out4, HIP_SYMBOL(e8_counters), sizeof(unsigned long long) * 4, 0, hipMemcpyDeviceToHost, s);
+        e != hipSuccess)
+        return e;
+    if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess) return e;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(e8_counters), z, sizeof(z), 0, hipMemcpyHostToDevice, s); e != hipSuccess) return e;
+        return hipStreamSynchronize(s);
+    }
+    return hipSuccess;
 }
 
 bool em8_covers(int k) {

@@ -53,7 +53,8 @@ struct ppca_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int n_cu = 256;
+    int n_cu = 256;         // workgroups a persistent-grid launch gets (= the device's CUs unless ppca_ctx_set_grid_limit capped it)
+    int n_cu_device = 256;  // the device's CUs
     std::shared_ptr<DevPool> pool;  // block cache behind dev_alloc while USE_CTX(this) is in scope
     bool timing = false;
     int skip_llk = 0;  // internal: set around the mixture's component EM steps (PassArgs::no_llk)

@@ -84,6 +84,9 @@ struct Em16Launch {
     int no_llk;
     double *dbg;
 };
+// diagnostic counters of the int8 statistics contraction (see ppca_em8.hip): read (and optionally reset) on the current device
+hipError_t em8_debug_counters(unsigned long long *out4, int reset, hipStream_t s);
+hipError_t em16_debug_counters(unsigned long long *out4, int reset, hipStream_t s);
 bool em16_covers(int d, int k);
 int em16_ncol(int k);
 size_t em16_qtab_bytes(int k);

@@ -381,5 +381,12 @@ class ShardedMixEM:
         from .api import PPCAMix
 
         if self._one_call:
-            return PPCAMix([PPCAModel._from_device(m, self.ctx, self.d, k) for m, k in zip(self.cur, self.ks)], self.log_weights)
+            # host copies only: cur / nxt are this object's ping-pong buffers and are overwritten two steps later, so a
+            # model handed out mid-training must never carry one of them as its cached device handle
+            models = []
+            for dev, k in zip(self.cur, self.ks):
+                sig, c, mean = C.c_double(0.0), np.empty((self.d, k)), np.empty(self.d)
+                check(lib().ppca_model_download(dev.h, C.byref(sig), ptr(c), ptr(mean)))
+                models.append(PPCAModel(sig.value, c, mean))
+            return PPCAMix(models, np.array(self.log_weights, dtype=np.float64))
         return PPCAMix(self.backend.models(), self.log_weights)

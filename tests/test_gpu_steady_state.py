@@ -1,0 +1,299 @@
+"""The STEADY STATE of the fused kernels under the oracle.
+
+The fused kernels start min(tiles, CUs) persistent workgroups, so at the sizes the CPU oracle affords (N <= 20 000) a
+workgroup of the 256-CU part walks at most three 32-sample tiles -- what only exists from tile 2-4 onwards (em8's
+three-tile mask ring and its two-blocks-deep pipelined contraction, the periodic flush of the int64 accumulators every
+100 groups, a raise of the fixed-point exponents with a contraction pending; em16's next-tile prefetch, LDS-parked factor
+and hand-over ring; the two-tile rounds of the llk sweep) would only ever be compared with itself.  Here:
+
+  * `ppca_ctx_set_grid_limit` (a test hook of the C-ABI) caps the grid at 1-2 workgroups, so N = 20 000 gives every
+    workgroup ~300 tiles, and every pass is compared with the literal oracle (ppca_model.rs:277-358 et al.);
+  * weights spanning 2^80 INSIDE one workgroup's run force the rescale path again and again -- asserted through the
+    kernels' diagnostic counters (`ppca_debug_counters`), not assumed;
+  * BASELINE config 2 at its full size (N = 1 M) against the oracle's one-sweep form (itself pinned to the literal port
+    in tests/test_oracle.py) and 200 000 rows against the literal port; the reference's largest shape (d = 200, k = 16)
+    likewise;
+  * BASELINE config 3's size (N = 10 M on one GPU: the periodic flush fires six times per workgroup) through
+    size-independent properties: 8-shard additivity, bit reproducibility, monotone llk, observed counts BIT-EXACT.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P(hiplib):
+    import ppca_rs_amd as p
+
+    return p
+
+
+@pytest.fixture()
+def ctx(P):
+    from ppca_rs_amd import _lib
+
+    c = _lib.default_context()
+    c.set_grid_limit(0)
+    c.debug_counters(reset=True)
+    yield c
+    c.set_grid_limit(0)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _blocks(d, k):
+    kp = k * (k + 1) // 2
+    b = [0, d * k, d * k + d * kp, 2 * d * k + d * kp, 2 * d * k + d * kp + d, 2 * d * k + d * kp + 2 * d]
+    return list(zip(["cross", "S", "U", "sumx", "totals", "scalars"], b, b[1:] + [b[-1] + 8]))
+
+
+def _stats(P, ds, m):
+    from ppca_rs_amd import _lib
+
+    got = np.empty(_lib.lib().ppca_stats_len(m.output_size, m.state_size))
+    _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
+    return got
+
+
+def _assert_stats(got, want, d, k, tol, tag):
+    for name, a, b in _blocks(d, k):
+        assert _rel(got[a:b], want[a:b]) < tol, (name,) + tuple(tag)
+
+
+def _gathered_stats(P, ctx, ds, m, u):
+    """One component pass of the mixture (ppca_mix_component_stats): weights exp(u - max u), rows of negligible weight
+    dropped and the others GATHERED -- em8_kernel<K, true, true>."""
+    import torch
+    from ppca_rs_amd import _lib
+
+    L = _lib.lib().ppca_stats_len(m.output_size, m.state_size)
+    ud = torch.from_numpy(u).cuda()
+    out = torch.empty(L, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    sm, used = C.c_double(0.0), C.c_int64(0)
+    _lib.check(_lib.lib().ppca_mix_component_stats(ctx.handle, ds._h, m._device(ctx).h, C.c_void_p(ud.data_ptr()), float(u.max()),
+                                                   C.c_void_p(out.data_ptr()), C.byref(sm), C.byref(used)))
+    return out.cpu().numpy(), sm.value, used.value
+
+
+@pytest.mark.parametrize("k,d", [(1, 64), (4, 200), (7, 255), (10, 256)])
+def test_eight_wave_em_pass_steady_state(P, oracle, ctx, k, d):
+    """em8_kernel (weighted, un-weighted and gathered instantiations) with ~300 tiles per workgroup: the three-tile mask
+    ring, the pipelined contraction, the tiles-cut counter and (beyond 200 tiles) the periodic int64 flush all fire; the
+    whole statistics buffer against the literal oracle."""
+    n = 20_000
+    rng = np.random.default_rng(500 + k)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 7000 + k)
+    x[n // 3] = np.nan  # an all-masked row in the middle of a run
+    c, mu, s = 0.6 * rng.standard_normal((d, k)), 0.2 * rng.standard_normal(d), 0.7
+    w = rng.uniform(0.25, 2.0, n)
+    m = P.PPCAModel(s, c, mu)
+    for cap in (2, 1):
+        ctx.set_grid_limit(cap)
+        for weights in (None, w):
+            ctx.debug_counters(reset=True)
+            got = _stats(P, P.Dataset(x, weights), m)
+            cnt = ctx.debug_counters()
+            assert cnt[2] >= (n // 32) // cap and cnt[1] >= 1, cnt  # tiles walked by one workgroup; periodic flushes
+            _assert_stats(got, oracle.stats(x, s, c, mu, weights), d, k, 1e-9, (k, cap, weights is None))
+        if cap == 2:
+            # gathered: a third of the rows dropped (weight exactly 0), the others with weights over 20 binary orders
+            u = np.log(w) + rng.uniform(-14.0, 0.0, n)
+            u[rng.random(n) < 0.33] = -np.inf
+            got, sm, used = _gathered_stats(P, ctx, P.Dataset(x), m, u)
+            wg = np.exp(u - u.max())
+            assert used == int((wg > 0).sum()) and used // 32 // cap > 150
+            assert abs(sm - wg.sum()) < 1e-12 * wg.sum()
+            want = oracle.stats(x, s, c, mu, wg)
+            for name, a, b in _blocks(d, k)[:-1]:
+                assert _rel(got[a:b], want[a:b]) < 1e-9, (name, k, "gathered")
+            assert _rel(got[-8:-4], want[-8:-4]) < 1e-9  # (the count of non-empty samples sees the gathered rows only)
+
+
+@pytest.mark.parametrize("k,d", [(1, 64), (4, 200), (7, 255), (10, 256)])
+def test_output_passes_steady_state(P, oracle, ctx, k, d):
+    """llk2_kernel (two-tile rounds) and pass_kernel<K, false> (states, covariances, smooth, extrapolate, covariance
+    diagonals) with ~300 tiles per workgroup against the oracle."""
+    n = 20_000
+    rng = np.random.default_rng(600 + k)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 7100 + k)
+    x[n // 2] = np.nan
+    c, mu, s = 0.6 * rng.standard_normal((d, k)), 0.2 * rng.standard_normal(d), 0.7
+    w = rng.uniform(0.25, 2.0, n)
+    m = P.PPCAModel(s, c, mu)
+    ds = P.Dataset(x, w)
+    ctx.set_grid_limit(2)
+    assert _rel(m.llks(ds), oracle.llks(x, s, c, mu)) < 1e-10
+    want = oracle.llk(x, s, c, mu, w)
+    assert abs(m.llk(ds) - want) < 1e-10 * abs(want)
+    st, cv = oracle.infer(x, s, c, mu)
+    inf = m.infer(ds)
+    assert _rel(inf.states(), st) < 1e-9 and _rel(np.array(inf.covariances()), cv) < 1e-9
+    assert _rel(m.smooth(ds).numpy(), oracle.reconstruct(x, s, c, mu, "smooth")) < 1e-9
+    ex = m.extrapolate(ds).numpy()
+    assert _rel(ex, oracle.reconstruct(x, s, c, mu, "extrapolate")) < 1e-9
+    assert np.array_equal(ex[np.isfinite(x)], x[np.isfinite(x)])
+    from ppca_rs_amd import _lib
+
+    for mode, name in ((0, "smooth"), (1, "extrapolate")):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ppca_covariance_diagonal(ctx.handle, ds._h, m._device(ctx).h, mode, C.byref(h)))
+        assert _rel(P.Dataset._wrap(h, ctx).numpy(), oracle.covariance_diagonal(x, s, c, mu, name)) < 1e-9
+
+
+@pytest.mark.parametrize("k,d", [(11, 256), (13, 200), (14, 255), (16, 200)])
+def test_two_kernel_em_pass_steady_state(P, oracle, ctx, k, d):
+    """estep16_kernel + sstat16_kernel with ~300 tiles per workgroup (next-tile prefetch, LDS-parked factor, hand-over
+    ring, flush cadence), weighted and un-weighted, and the output passes of these shapes, against the oracle."""
+    n = 20_000
+    rng = np.random.default_rng(700 + k)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 7200 + k)
+    x[n // 3] = np.nan
+    c, mu, s = 0.5 * rng.standard_normal((d, k)), 0.2 * rng.standard_normal(d), 0.7
+    w = rng.uniform(0.25, 2.0, n)
+    m = P.PPCAModel(s, c, mu)
+    for cap in (2, 1):
+        ctx.set_grid_limit(cap)
+        for weights in (None, w):
+            ctx.debug_counters(reset=True)
+            got = _stats(P, P.Dataset(x, weights), m)
+            cnt = ctx.debug_counters()
+            assert cnt[6] >= (n // 32) // cap and cnt[5] >= 1, cnt
+            _assert_stats(got, oracle.stats(x, s, c, mu, weights), d, k, 1e-9, (k, cap, weights is None))
+    ctx.set_grid_limit(2)
+    ds = P.Dataset(x, w)
+    assert _rel(m.llks(ds), oracle.llks(x, s, c, mu)) < 1e-10
+    st, cv = oracle.infer(x, s, c, mu)
+    inf = m.infer(ds)
+    assert _rel(inf.states(), st) < 1e-9 and _rel(np.array(inf.covariances()), cv) < 1e-9
+    assert _rel(m.smooth(ds).numpy(), oracle.reconstruct(x, s, c, mu, "smooth")) < 1e-9
+    assert _rel(m.extrapolate(ds).numpy(), oracle.reconstruct(x, s, c, mu, "extrapolate")) < 1e-9
+    assert _rel(inf.smoothed_covariances_diagonal(m).numpy(), oracle.covariance_diagonal(x, s, c, mu, "smooth")) < 1e-9
+
+
+@pytest.mark.parametrize("k,d", [(4, 64), (10, 256), (12, 64), (16, 200)])
+def test_fixed_point_form_rescales_inside_one_workgroup(P, oracle, ctx, k, d):
+    """Weights spanning 2^80 over ONE workgroup's rows (grid capped at 1): ascending, a column outgrows its exponent every
+    few tiles -- contract what is pending under the old exponents, flush the int64 accumulators into the partial, raise
+    the exponents, cut the tile again --, asserted through the rescale counter; descending, the exponents stay where the
+    first tile put them and the later rows are cut far below it (precision relative to the LARGEST terms, as in any fp64
+    sum).  em8_kernel's back role (k <= 10) and sstat16_kernel (k >= 11), against the oracle."""
+    n = 6_000
+    rng = np.random.default_rng(800 + k)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 7300 + k)
+    c, mu, s = 0.4 * rng.standard_normal((d, k)), 0.1 * rng.standard_normal(d), 0.8
+    m = P.PPCAModel(s, c, mu)
+    ctx.set_grid_limit(1)
+    base = 0 if k <= 10 else 4
+    for asc in (True, False):
+        w = 2.0 ** np.linspace(-40, 40, n)
+        w = w if asc else w[::-1].copy()
+        ctx.debug_counters(reset=True)
+        got = _stats(P, P.Dataset(x, w), m)
+        cnt = ctx.debug_counters()
+        assert cnt[base + 2] == (n + 31) // 32
+        if asc:
+            assert cnt[base] >= 8, cnt  # 80 binary orders at 6 orders of head room per rescale
+        else:
+            assert cnt[base] == 0, cnt
+        _assert_stats(got, oracle.stats(x, s, c, mu, w), d, k, 1e-9, (k, asc))
+
+
+def _generated(P, ctx, n, d, k, seed, mask_prob=0.3):
+    from ppca_rs_amd import _lib
+
+    truth = P.PPCAModel(0.1, np.random.default_rng(seed).standard_normal((d, k)), np.random.default_rng(seed + 1).standard_normal(d))
+    spec = _lib.SynthSpec(0, n, d, k, 0.1, mask_prob, 0, 0, 1000 + seed, truth._c.ctypes.data_as(_lib.c_double_p),
+                          truth._mean.ctypes.data_as(_lib.c_double_p))
+    h = C.c_void_p()
+    _lib.check(_lib.lib().ppca_dataset_generate(ctx.handle, C.byref(spec), C.byref(h)))
+    return P.Dataset._wrap(h, ctx)
+
+
+@pytest.mark.parametrize("d,k", [(256, 10), (200, 16)])
+def test_full_size_statistics_against_oracle(P, oracle, ctx, d, k):
+    """BASELINE config 2 at its own size (N = 1 M, d = 256, k = 10, 30 % masked; 122 tiles per workgroup on the full
+    grid) and the reference's largest shape (d = 200, k = 16, lib.rs:82-99): the statistics buffer of one EM pass
+    against the oracle's one-sweep form on all rows, and against the LITERAL port (four sweeps, ppca_model.rs:277-358)
+    on the first 200 000."""
+    n = 1_000_000
+    ds = _generated(P, ctx, n, d, k, 31 + k)
+    m = P.PPCAModel.init(k, ds, seed=5)
+    m = m.iterate(ds)  # (a model one step away from the random start)
+    s, c, mu = m.isotropic_noise, m.transform, m.mean
+    x = ds.numpy()
+    got = _stats(P, ds, m)
+    _assert_stats(got, oracle.fused_stats(x, s, c, mu), d, k, 1e-9, (d, k, "one-sweep"))
+    sub = ds._slice(0, 200_000)
+    _assert_stats(_stats(P, sub, m), oracle.stats(x[:200_000], s, c, mu), d, k, 1e-9, (d, k, "literal"))
+
+
+def test_full_size_properties_config3(P, ctx):
+    """BASELINE config 3's size on one GPU (N = 10 M, d = 256, k = 10, 30 % masked: 1 221 tiles per workgroup, the
+    periodic flush fires six times in each): 8-shard additivity (the multi-GPU invariant), run-to-run bit
+    reproducibility, monotone llk, and the per-dimension observed counts -- sums of 0/1 through the int8 / int64 path --
+    BIT-EXACT against a scan of the data by torch."""
+    import torch
+    from ppca_rs_amd import _lib
+
+    n, d, k = 10_000_000, 256, 10
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ct = torch.randn(d, k, dtype=torch.float64, device="cuda", generator=g)
+    X = torch.empty(n, d, dtype=torch.float64, device="cuda")
+    step = 1_000_000
+    for a in range(0, n, step):
+        z = torch.randn(step, k, dtype=torch.float64, device="cuda", generator=g)
+        blk = z @ ct.T + 0.1 * torch.randn(step, d, dtype=torch.float64, device="cuda", generator=g)
+        blk[torch.rand(step, d, device="cuda", generator=g) < 0.3] = float("nan")
+        X[a:a + step] = blk
+    del z, blk
+    counts = torch.isfinite(X).sum(dim=0).double().cpu().numpy()
+    torch.cuda.synchronize()
+    ds = P.Dataset.from_device(X.data_ptr(), n, d, ctx=ctx, keepalive=X)
+    m = P.PPCAModel.init(k, ds, seed=11)
+    prev = -np.inf
+    for _ in range(3):
+        m, llk = m.iterate_with_llk(ds)
+        assert np.isfinite(llk) and llk >= prev
+        prev = llk
+    ctx.debug_counters(reset=True)
+    full = _stats(P, ds, m)
+    cnt = ctx.debug_counters()
+    assert cnt[1] >= 6 * 256 and cnt[2] == 1221, cnt
+    np.testing.assert_array_equal(full, _stats(P, ds, m))
+    L = len(full)
+    o_tot = 2 * d * k + d * (k * (k + 1) // 2) + d
+    np.testing.assert_array_equal(full[o_tot:o_tot + d], counts)
+    acc = np.zeros(L)
+    for ch in ds.chunks(8):
+        acc += _stats(P, ch, m)
+    assert _rel(acc, full) < 1e-11
+    np.testing.assert_array_equal(acc[o_tot:o_tot + d], counts)
+
+
+def test_sharded_mixture_hands_out_detached_models(P, ctx):
+    """ShardedMixEM ping-pongs between two private device models per component; a mixture handed out mid-training must
+    not alias them (two steps later the buffer holds another iterate): its llk stays what it was."""
+    from ppca_rs_amd.distributed import ShardedMixEM
+
+    rng = np.random.default_rng(9)
+    d, k, nm, n = 24, 3, 3, 3000
+    parts = [P.PPCAModel(0.2, rng.standard_normal((d, k)), 3.0 * rng.standard_normal(d)).sample(n // nm, 0.2, seed=40 + c) for c in range(nm)]
+    ds = P.Dataset.concat(parts)
+    em = ShardedMixEM(ds, P.PPCAMix.init(nm, k, ds, seed=2))
+    em.step()
+    mid = em.mixture()
+    before = mid.llk(ds)
+    host = [np.array(m.transform) for m in mid.models]
+    for _ in range(3):
+        em.step()
+    assert mid.llk(ds) == before
+    for m, c in zip(mid.models, host):
+        np.testing.assert_array_equal(m.transform, c)
+    assert em.mixture().llk(ds) > before
