@@ -737,8 +737,9 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
     if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
     fused_qtab_layout(ctx->qtab->p, a);
 #ifdef PPCA_PHASE_TIMING
-    BufRef dbg;
-    if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 16, &dbg)) return rc;
+    BufRef dbg;  // [grid][16] phase sums of one thread per role, then [grid][8 waves][16] per-wave sums (em8_kernel)
+    if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 144, &dbg)) return rc;
+    HIP_TRY(hipMemsetAsync(dbg->p, 0, sizeof(double) * (size_t)grid * 144, ctx->stream));
     a.dbg = static_cast<double *>(dbg->p);
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -755,9 +756,23 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
     HIP_TRY(launch_reduce_partials(a.part, grid, L.len, stats_dev, ctx->stream));
 #ifdef PPCA_PHASE_TIMING
     {
-        std::vector<double> h((size_t)grid * 16);
+        std::vector<double> h((size_t)grid * 144);
         HIP_TRY(hipMemcpyAsync(h.data(), a.dbg, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        {
+            const double tl = (double)((n + FUSED_TILE - 1) / FUSED_TILE) / grid;
+            static const char *fn[16] = {"P2", "wait-back", "stores", "barrier", "P3-load", "barrier", "factor", "solve", "columns", "scalars",
+                                         "wg-barrier", "P4a", "barrier", "staging", "barrier", "-"};
+            static const char *bn[16] = {"wg-barrier", "digitise", "barrier", "contract", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"};
+            for (int w = 0; w < 8; ++w) {
+                double tw[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int g = 0; g < grid; ++g)
+                    for (int i = 0; i < 16; ++i) tw[i] += h[(size_t)grid * 16 + ((size_t)g * 8 + w) * 16 + i] / grid;
+                fprintf(stderr, "[em8 wave %d cycles/tile]", w);
+                for (int i = 0; i < (w < 4 ? 15 : 4); ++i) fprintf(stderr, " %s %.0f", w < 4 ? fn[i] : bn[i], tw[i] / tl);
+                fprintf(stderr, "\n");
+            }
+        }
         double t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int g = 0; g < grid; ++g)
             for (int i = 0; i < 16; ++i) t[i] += h[(size_t)g * 16 + i] / grid;

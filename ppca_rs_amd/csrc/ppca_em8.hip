@@ -60,6 +60,16 @@ constexpr int E8_FLUSH_GROUPS = 100;
 #ifndef E8_FRONT_PRIO
 #define E8_FRONT_PRIO 0
 #endif
+#ifndef E8_GS_PAD
+#define E8_GS_PAD 18  // row stride of [G | b] / W rows = 16 NTP + 18 doubles: even, so that the solver's lane-per-sample accesses
+                      // pair up into 16-byte LDS operations that spread over all banks (measured: 17 costs 2 %)
+#endif
+#ifndef E8_DECOUPLED
+#define E8_DECOUPLED 0  // 1: the roles meet through LDS counters only; 0: a workgroup barrier per tile after P3 (round 3)
+#endif
+#ifndef E8_SHARED_FACTOR
+#define E8_SHARED_FACTOR 0  // 0: every front wave factors every sample (rounds 1-3)
+#endif
 
 // Diagnostic counters of the back role (tests prove with them that the cold path and the periodic flush ran): [0] tiles cut
 // again after a rescale of the fixed-point exponents (beyond a workgroup's first), [1] periodic flushes of the int64
@@ -77,7 +87,7 @@ struct Cfg8 {
     // four front waves hold them in registers (a front barrier inside P3), its W row is written after that.
     //   as [G | b]:  G (16 NTP, K' used) | b partial of dims 0-127 (16) | pad
     //   as W row:    wP (K') ..          | wz (K) | w | 0 ..
-    static constexpr int GS = 16 * NTP + 18;
+    static constexpr int GS = 16 * NTP + E8_GS_PAD;
     static constexpr int WS = GS;
     static constexpr int BS = K + 1;             // b partial of dims 128-255
     static constexpr int PLANE_BYTES = E8_QW * 2 * NCOL * 16;  // digit planes of one tile: [plane][16-sample chunk][column][16 B]
@@ -115,6 +125,9 @@ __device__ __forceinline__ void role_barrier(unsigned *ctr, unsigned &target, in
     asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void wait_counter(const unsigned *ctr, unsigned need) {
+#if defined(E8_ONLY_FRONT) || defined(E8_ONLY_BACK)  // timing experiments with one role absent: nothing to wait for
+    return;
+#endif
     for (;;) {
         const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if ((int)(seen - need) >= 0) break;
@@ -125,8 +138,13 @@ __device__ __forceinline__ void wait_counter(const unsigned *ctr, unsigned need)
 
 #ifdef PPCA_PHASE_TIMING
 #define E8_STAMP(i) { long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+#define E8_FINE(i) { long long tn = clock64(); tfine[i] += tn - tfl; tfl = tn; }  // per-wave table (PPCA_PHASE_TIMING)
+#elif defined(PPCA_MARKS)  // tools/devbuild.py -DPPCA_MARKS --asm: phase boundaries as comments in the ISA listing
+#define E8_STAMP(i) asm volatile("; E8_MARK " #i ::: "memory");
+#define E8_FINE(i)
 #else
 #define E8_STAMP(i)
+#define E8_FINE(i)
 #endif
 
 // WEIGHTED: the dataset carries sample weights (PassArgs::w).  A template parameter because the weighted pass takes a
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     double *scl = sm + cfg::OFF_L;
     int *Ex = reinterpret_cast<int *>(sm + cfg::OFF_E);
     unsigned *ctr = reinterpret_cast<unsigned *>(sm + cfg::OFF_BAR);
-    unsigned *fbar = ctr, *bbar = ctr + 1, *digdone = ctr + 2, *vstamp = ctr + 3;
+    unsigned *fbar = ctr, *bbar = ctr + 1, *digdone = ctr + 2, *vstamp = ctr + 3, *wready = ctr + 4, *itdone = ctr + 5;
 
     if (p.qflag) {  // qprep's dynamic-range guard: the fp64-Gram pass_kernel runs instead
         int unsafe = 0;
@@ -188,6 +206,9 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     for (int idx = tid; idx < L_DEV + 6 * B; idx += 512) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
     for (int idx = tid; idx < cfg::DP * 4; idx += 512) Mb[idx] = 0u;
     for (int idx = tid; idx < cfg::DP; idx += 512) sm[cfg::OFF_MU + idx] = idx < d ? mMean[idx] : 0.0;
+#ifdef E8_ONLY_BACK
+    for (int idx = tid; idx < B * GS; idx += 512) Gs[idx] = 1.0;  // (something finite for the back role to cut)
+#endif
     if (tid < 8) ctr[tid] = 0u;
     if (tid == 0) {
         sm[cfg::OFF_K] = s2_k;
@@ -202,6 +223,8 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
 #ifdef PPCA_PHASE_TIMING
     long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
+    long long tfine[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tfl = tlast;
 #endif
     __syncthreads();
 
@@ -213,13 +236,22 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
 #endif
     if (!front) {
         // =========================================================== back role: P4b on the int8 MFMA
-        long long accM[RT][NCT][4];
+#ifndef E8_ACC_F64
+#define E8_ACC_F64 0  // 1: the group's exact 24-bit pieces are added to fp64 accumulators (one rounding per piece: three per group
+                      //    of 64 samples, where a plain fp64 sum takes 64); 0: to int64 accumulators (exact; rounds 3)
+#endif
+#if E8_ACC_F64
+        typedef double acc_t;
+#else
+        typedef long long acc_t;
+#endif
+        acc_t accM[RT][NCT][4];
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
             for (int t = 0; t < NCT; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) accM[r][t][q] = 0ll;
+                for (int q = 0; q < 4; ++q) accM[r][t][q] = (acc_t)0;
         // (measured: the back role at a higher priority than the front costs 5 % -- it is off the front's critical path
         //  and only has to fill the gaps)
         if (E8_BACK_PRIO) __builtin_amdgcn_s_setprio(E8_BACK_PRIO);
@@ -340,7 +372,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                         const int dim = DW * wave + 16 * r + 4 * l4 + q;
                         double v = have_scale ? (double)accM[r][t][q] * fsc : 0.0;
                         if (E > 5000) v = fsc;  // poisoned column: NaN whatever the integers hold
-                        if (clear) accM[r][t][q] = 0ll;
+                        if (clear) accM[r][t][q] = (acc_t)0;
                         if (dim < d && c < NC) {
                             double *dst = c < KP ? out + L.S + (int64_t)dim * KP + c
                                                  : (a < K ? out + L.U + (int64_t)dim * K + a : out + L.totals + dim);
@@ -396,9 +428,23 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 const i4_t *d3 = dd[i & 1];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {  // D row = 4 l4 + q (dim 16 r + 4 l4 + q), column l15
+#if E8_ACC_F64
+                    // the piece (|.| < 2^30) converts exactly; piece x 2^(24 batch) is exact; ONE rounding in the add.
+                    // (v_lshl_add_u32 by hand: hipcc reassociates the Horner form into two shifts and a three-way add)
+                    if constexpr (batch < 2) {
+                        int pc;
+                        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(pc) : "v"(d3[2][q]), "v"(d3[1][q]));
+                        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(pc) : "v"(pc), "v"(d3[0][q]));
+                        if constexpr (batch == 0) accM[r][t][q] += (double)pc;
+                        else accM[r][t][q] = __builtin_fma((double)pc, 0x1p24, accM[r][t][q]);
+                    } else {
+                        accM[r][t][q] = __builtin_fma((double)d3[0][q], 0x1p48, accM[r][t][q]);
+                    }
+#else
                     if constexpr (batch == 0) accM[r][t][q] += (long long)((((d3[2][q] << 8) + d3[1][q]) << 8) + d3[0][q]);  // |.| < 2^30
                     else if constexpr (batch == 1) accM[r][t][q] += (long long)((((d3[2][q] << 8) + d3[1][q]) << 8) + d3[0][q]) << 24;
                     else accM[r][t][q] += (long long)d3[0][q] << 48;
+#endif
                 }
             };
             issue(std::integral_constant<int, 0>{});
@@ -415,15 +461,25 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             const int rel = (int)(tile - tile_begin);
             const bool last = tile + 1 == tile_end;
             const int slot_cur = rel % 3, slot_prev = (rel + 2) % 3;
-            __syncthreads();  // front: P3(tile) done -> the tile's W rows are final
+            // front: P3(tile) done in all four waves -> the tile's W rows are final.  A counter, not a workgroup barrier: the
+            // front never waits for this role here (the contraction of a group is two tiles' work on every second
+            // tile: behind a barrier the front stood ~2.6 k cycles on those tiles)
+#if E8_DECOUPLED
+            wait_counter(wready, 4u * (unsigned)(rel + 1));
+#else
+            __syncthreads();
+#endif
             E8_STAMP(5)
+            E8_FINE(0)
 #pragma unroll 1
             for (;;) {  // normally one trip
                 ++attempt;
                 const bool bad = !have_scale || digitise(lane, pending ? PG_BYTES : P0_BYTES);
                 if (bad && lane == 0) __hip_atomic_store(vstamp, attempt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                E8_FINE(1)
                 role_barrier(bbar, bbar_target, lane_entry);
                 E8_STAMP(6)
+                E8_FINE(2)
                 const bool viol = __builtin_amdgcn_readfirstlane(__hip_atomic_load(vstamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == attempt;
                 // What is contracted now: a fitting tile completes its group (or is the last tile: alone); a tile that does
                 // not fit sends what is pending in alone, under the old exponents -- then (cold path) the integers leave
@@ -435,6 +491,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 if (con) {
                     contract(lane, !viol && pending, pending ? slot_prev : slot_cur, slot_cur);
                     ++groups;
+                    E8_FINE(3)
                 }
                 pending = (!viol && !con) ? 1 : 0;
                 if (viol ? have_scale != 0 : groups >= E8_FLUSH_GROUPS) {
@@ -450,6 +507,10 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 have_scale = 1;
                 role_barrier(bbar, bbar_target, lane_entry);
             }
+            // this wave has read the sample masks and planes of its iteration for the last time (the front waits for this
+            // before it stages the tile that reuses the oldest mask slot)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane_entry == 0) __hip_atomic_fetch_add(itdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             E8_STAMP(7)
         }
         emit(lane_entry, flushed != 0, false);
@@ -462,6 +523,8 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
 #ifdef PPCA_PHASE_TIMING
         if (p.dbg && tid == 256)
             for (int i = 5; i < 8; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
+        if (p.dbg && lane_entry == 0)
+            for (int i = 0; i < 16; ++i) p.dbg[(int64_t)gridDim.x * 16 + ((int64_t)blockIdx.x * 8 + wave8) * 16 + i] = (double)tfine[i];
 #endif
         return;
     }
@@ -689,9 +752,11 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             group(qbA, false);  // digits {3,2}
             group(qbB, false);  // digits {1,0}
             E8_STAMP(0)
+            E8_FINE(0)
             // [G | b] shares its buffer with the previous tile's W rows: wait until the back role has cut them (long done:
             // the cut is the first thing the back does after the workgroup barrier)
             wait_counter(digdone, 4u * (unsigned)rel);
+            E8_FINE(1)
             if (gram_wave) {
 #pragma unroll
                 for (int rt2 = 0; rt2 < 2; ++rt2)
@@ -706,8 +771,10 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 else if (l15 < K + 1) B1[(16 * rt + l4 + 4 * r) * BS + l15] = accb[r];
             }
         }
+        E8_FINE(2)
         role_barrier(fbar, fbar_target, lane_entry);
         E8_STAMP(1)
+        E8_FINE(3)
         // ------------------------------------------------------------ P3: per-sample k x k solve
         // Every front wave factors every sample (lane = sample, lanes 32-63 mirror 0-31) and the waves share the
         // independent columns of M^-1, two per instruction stream (lane i: column 2p, lane i + 32: column 2p + 1);
@@ -727,16 +794,61 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             double *wrow = Ws + i * WS;
             double sc_sq = 0.0, sc_dev = 0.0, sc_llk = 0.0, sc_w = 0.0, sc_ne = 0.0;
             Posterior<K> post;
-            double pm;
-            int pe;
-            double z[K], quad, zz;
+            double pm = 1.0;
+            int pe = 0;
+            double z[K], quad = 0.0, zz = 0.0;
+#if E8_SHARED_FACTOR
+            // ONE front wave -- rotating with the tile, so that every SIMD carries the solver once in four tiles -- factors
+            // the tile's samples and solves for z; the factor, z and the by-products (quad, |z|^2, det M) go back into the
+            // sample's [G | b] row, where the other waves pick up what their columns of M^-1 need.  (Rounds 1-3: every
+            // front wave factored every sample: 3 x (328 + 140) vector instructions per tile on a port that is the
+            // kernel's bound.)
+            constexpr int XB = 16 * NTP + 12;  // free slots of the row (the b partial used K + 1 <= 11 of its 16)
+            if (wave == (rel & (NF - 1))) {
+                Posterior<K> fac;
+                double y[K], fq, fz, fm;
+                int fe;
+                fac.load([&](int e) { return g0[e]; }, s2);
+#pragma unroll
+                for (int a = 0; a < K; ++a) y[a] = g0[16 * NTP + a] + b1[a];
+                fac.factor_loaded(fm, fe);
+                fac.solve_loaded(y, fq, fz);
+                if (hi == 0) {
+                    double *g0w = Gs + i * GS;
+#pragma unroll
+                    for (int e = 0; e < KP; ++e) g0w[e] = fac.L[e];
+#pragma unroll
+                    for (int a = 0; a < K; ++a) g0w[16 * NTP + a] = y[a];
+                    g0w[XB] = fq;
+                    g0w[XB + 1] = fz;
+                    g0w[XB + 2] = fm;
+                    g0w[XB + 3] = (double)fe;
+                }
+            }
+            role_barrier(fbar, fbar_target, lane_entry);
+#pragma unroll
+            for (int e = 0; e < KP; ++e) post.L[e] = g0[e];
+#pragma unroll
+            for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a];
+            quad = g0[XB];
+            zz = g0[XB + 1];
+            pm = g0[XB + 2];
+            pe = (int)g0[XB + 3];
+            // the W rows go where [G | b] is: every front wave holds its operands before any of them writes a row
+            role_barrier(fbar, fbar_target, lane_entry);
+#else
             post.load([&](int e) { return g0[e]; }, s2);
 #pragma unroll
             for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a] + b1[a];
             // the W rows go where [G | b] is: every front wave holds its operands before any of them writes a row
+            E8_FINE(4)
             role_barrier(fbar, fbar_target, lane_entry);
+            E8_FINE(5)
             post.factor_loaded(pm, pe);
+            E8_FINE(6)
             post.solve_loaded(z, quad, zz);
+            E8_FINE(7)
+#endif
             double trpart = 0.0;
             if constexpr (PAIRS) {
 #pragma unroll
@@ -756,15 +868,21 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                     trpart += post.minv_column(c, [&](int a, int cc, double v) { wrow[tri(a, cc)] = wgt * (z[a] * z[cc] + s2 * v); });
                 }
             }
+            E8_FINE(8)
             // tr(C_o Sigma C_o^T) = <Sigma, G> = s2 (K - s2 tr M^-1)  (:345); all-masked samples are filtered out (:333)
             if (m > 0) sc_sq -= wgt * s2 * s2 * trpart;
-            if (wave == 0 && hi == 0) {
-                const double run_dev = scl[L_DEV + i], run_llk = scl[L_LLK + i], run_w = scl[L_W + i], run_ne = scl[L_NE + i];
-                const double run_pm = scl[L_PM + i], run_px = scl[L_PX + i];
-                double *zrow = wrow + 16 * NTP;  // W row = [w P (K') | 0.. | w z (K) | w | 0..]
+            if (hi == 0) {
+                // W row = [w P (K') | 0.. | w z (K) | w | 0..].  EVERY front wave writes the [w z | w] part (the same values:
+                // each has solved for z): P4a then reads what the wave itself wrote, and no front wave waits for another
+                // between P3 and P4a.
+                double *zrow = wrow + 16 * NTP;
 #pragma unroll
                 for (int a = 0; a < K; ++a) zrow[a] = wgt * z[a];
                 zrow[K] = wgt;
+            }
+            if (wave == 0 && hi == 0) {
+                const double run_dev = scl[L_DEV + i], run_llk = scl[L_LLK + i], run_w = scl[L_W + i], run_ne = scl[L_NE + i];
+                const double run_pm = scl[L_PM + i], run_px = scl[L_PX + i];
                 if (m > 0) {
                     sc_sq += wgt * s2 * (double)K;
                     sc_dev += wgt * (0.0 - quad - s2 * zz);  // |x~ - C_o z|^2 minus |x~|^2, added in the epilogue (:346)
@@ -789,7 +907,15 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             scl[wave * SQW + (PAIRS ? lane : i)] += sc_sq;  // (read here, not at the top: the value would sit in a spilled register across the solve)
         }
         E8_STAMP(2)
-        __syncthreads();  // the tile's W rows are final: the back role starts on them
+        E8_FINE(9)
+        // this wave's part of the tile's W rows is final: the back role starts on them when all four have said so
+#if E8_DECOUPLED
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane_entry == 0) __hip_atomic_fetch_add(wready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        __syncthreads();
+#endif
+        E8_FINE(10)
         // ------------------------------------------------------------ P4a: cross / sumx += X~^T [wz | w]
         // the only reader of the x~ tile; the next tile's rows are requested one per k-step behind the MFMAs
         {
@@ -822,16 +948,27 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        E8_FINE(11)
         role_barrier(fbar, fbar_target, lane_entry);  // the x~ tile is free
         E8_STAMP(3)
+        E8_FINE(12)
         // ------------------------------------------------------------ P1 of the next tile
+        // (its sample masks go into the slot of tile - 2: the back role's iterations up to tile - 1 must be over -- it
+        //  normally is one digitise into iteration `tile`)
+#if E8_DECOUPLED
+        wait_counter(itdone, 4u * (unsigned)rel);
+#endif
         stage_tile(tile + 1, lane);
+        E8_FINE(13)
         role_barrier(fbar, fbar_target, lane_entry);
         E8_STAMP(4)
+        E8_FINE(14)
     }
 #ifdef PPCA_PHASE_TIMING
     if (p.dbg && tid == 0)
         for (int i = 0; i < 5; ++i) p.dbg[(int64_t)blockIdx.x * 16 + 8 + i] = (double)tph[i];
+    if (p.dbg && lane_entry == 0)
+        for (int i = 0; i < 16; ++i) p.dbg[(int64_t)gridDim.x * 16 + ((int64_t)blockIdx.x * 8 + wave8) * 16 + i] = (double)tfine[i];
 #endif
 
     // ---------------------------------------------------------------- epilogue (front waves)

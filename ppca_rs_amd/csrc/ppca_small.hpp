@@ -258,6 +258,13 @@ PPCA_HD constexpr int pair_owner(int K, int p, int nw) {
     return own;
 }
 
+// true when no earlier pair belongs to pair p's owner (that pair's part of the factor covers the owner's later pairs)
+PPCA_HD constexpr bool pair_first_of_owner(int K, int p, int nw) {
+    for (int q = 0; q < p; ++q)
+        if (pair_owner(K, q, nw) == pair_owner(K, p, nw)) return false;
+    return true;
+}
+
 // Per-sample log-likelihood from the solve's by-products (ppca_model.rs:124-139):
 //   -1/2 [ (|x~|^2 - b^T M^-1 b)/s2 + ln det M + 2 ln(sigma)(m - k) + ln(2 pi) m ],  0 if m == 0
 PPCA_HD double sample_llk(double xx, double quad, double logdet, double s2, double ln_sigma, int m, int k) {

@@ -113,7 +113,8 @@ def test_eight_wave_em_pass_steady_state(P, oracle, ctx, k, d):
             want = oracle.stats(x, s, c, mu, wg)
             for name, a, b in _blocks(d, k)[:-1]:
                 assert _rel(got[a:b], want[a:b]) < 1e-9, (name, k, "gathered")
-            assert _rel(got[-8:-4], want[-8:-4]) < 1e-9  # (the count of non-empty samples sees the gathered rows only)
+            # scalars: a component pass skips the log-likelihood (PassArgs::no_llk) and counts the gathered rows only
+            assert _rel(got[[-8, -7, -5]], want[[-8, -7, -5]]) < 1e-9
 
 
 @pytest.mark.parametrize("k,d", [(1, 64), (4, 200), (7, 255), (10, 256)])
@@ -265,7 +266,7 @@ def test_full_size_properties_config3(P, ctx):
     ctx.debug_counters(reset=True)
     full = _stats(P, ds, m)
     cnt = ctx.debug_counters()
-    assert cnt[1] >= 6 * 256 and cnt[2] == 1221, cnt
+    assert cnt[1] >= 6 * 255 and cnt[2] == 1221, cnt  # (the last workgroup's run is shorter)
     np.testing.assert_array_equal(full, _stats(P, ds, m))
     L = len(full)
     o_tot = 2 * d * k + d * (k * (k + 1) // 2) + d
