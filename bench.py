@@ -45,6 +45,12 @@ def algorithmic_flops_per_sample(d: int, k: int, m: float) -> float:
     return 4 * m * kp + 4 * m * k + 2 * d * k + 2 * k ** 3
 
 
+def algorithmic_flops_llk_per_sample(k: int, m: float) -> float:
+    """One log-likelihood evaluation (ppca_model.rs:124-139): Gram 2 m k', b 2 m k, Cholesky k^3 / 3, forward substitution k^2."""
+    kp = k * (k + 1) / 2
+    return 2 * m * kp + 2 * m * k + k ** 3 / 3 + k ** 2
+
+
 def cargo_probe() -> dict:
     """record whether the reference's own toolchain exists on this box (it cannot build
     here either way: no network for the crates)."""
@@ -421,10 +427,18 @@ def main() -> None:
             # K x the flops of a k = 10 EM iteration (what the reference's K weighted iterate() calls perform; the
             # responsibility-sparse component passes skip the rows whose weight is below 2^-200 of the component's largest)
             bytes_step = rows_local * algorithmic_bytes_per_sample(d)
-            flops_step = nm * rows_local * algorithmic_flops_per_sample(d, k, m_obs)
             t_step = elapsed / args.steps
+            # What the step EXECUTED (never K x N x the EM flops: the component passes gather only the rows whose weight is not
+            # negligible -- the device-side row counts of the last timed step): K log-likelihood sweeps over every row + the
+            # gathered EM passes
+            used = (C.c_int64 * nm)()
+            _lib.check(_lib.lib().ppca_mix_last_rows_used(ctx.handle, used, nm))
+            rows_gathered = [int(v) for v in used]
+            flops_step = (nm * rows_local * algorithmic_flops_llk_per_sample(k, m_obs)
+                          + sum(rows_gathered) * algorithmic_flops_per_sample(d, k, m_obs))
+            flops_reference = nm * rows_local * (algorithmic_flops_llk_per_sample(k, m_obs) + algorithmic_flops_per_sample(d, k, m_obs))
             tflops, gbs = flops_step / t_step / 1e12, bytes_step / t_step / 1e9
-            fp64_bound = flops_step / (FP64_PEAK_TFLOPS * 1e12) >= bytes_step / (HBM_PEAK_GBS * 1e9)
+            fp64_bound = False  # the mixture is reported against the ONE-pass byte figure (X read once per iteration)
             kernel_name = (f"one mixture EM iteration = {nm} llk2_kernel<{k}> sweeps + {nm} gathered em8_kernel<{k}, true> passes + "
                            "finalisations (timed as one region: ONE C-ABI call)")
             kern_avg_ms, launches_rep = 1e3 * t_step, args.steps
@@ -488,6 +502,13 @@ def main() -> None:
             "note": "bound = the larger of (algorithmic bytes / HBM peak) and (algorithmic fp64 flops / dense fp64 MFMA peak) "
                     "per sample (SURVEY.md 8d): 0.261 ns vs 0.687 ns at d=256, k=10, so the fp64 pipe; hbm_* = the other one",
         }
+        if mixture:
+            roofline["note"] = ("frac = SURVEY.md 8(d)'s ONE-pass bytes (N x 2088 B: X read once per iteration) / step time / HBM peak; "
+                                "fp64_* = the flops the step EXECUTED (K llk sweeps over all rows + the EM flops of the rows each "
+                                "component pass gathered), not K x N x the EM flops the reference's K weighted iterate() calls perform")
+            roofline["rows_gathered_last_step"] = rows_gathered
+            roofline["rows_gathered_fraction_of_K_x_N"] = sum(rows_gathered) / float(nm * rows_local)
+            roofline["reference_equivalent_flops_per_step"] = flops_reference
         if mixture:
             workload = (f"PPCA mixture EM, {args.components} components, N={n} samples x d={d}, state_size={k}, "
                         f"{int(100 * args.mask)}% iid masked, {world} contiguous row shard(s); per step one all-reduce(MAX) of "

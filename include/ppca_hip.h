@@ -253,6 +253,11 @@ int ppca_mix_em_step_sharded(ppca_comm *comm, ppca_dataset *shard, ppca_model *c
                              const double *log_weights_in, int32_t n_models, const ppca_prior *prior,
                              ppca_model *const *models_out, double *log_weights_out, double *llk_in);
 
+/* Rows of this context's shard that each component pass of the most recent ppca_mix_em_step / ppca_mix_em_step_sharded
+ * gathered (the others carried a weight below 2^-200 of the component's largest, see ppca_mix_component_stats): what the
+ * step EXECUTED, for measurement (bench.py --config 5). */
+int ppca_mix_last_rows_used(ppca_ctx *ctx, int64_t *rows, int32_t n_models);
+
 /* ---------------------------------------------------------------- mixture */
 /* PPCAMix::iterate_with_prior mix.rs:281-337 on one GPU: per-sample
  * responsibilities (log-softmax of llk_c + log pi_c, :283-295), per-component

@@ -100,6 +100,7 @@ SIGNATURES = {
     "ppca_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_void_pp]),
     "ppca_covariance_diagonal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_void_pp]),
     "ppca_mix_em_step": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, C.POINTER(Prior), c_void_pp, C.c_void_p, c_double_p]),
+    "ppca_mix_last_rows_used": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "ppca_mix_llk": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, c_double_p, C.c_void_p, C.c_void_p]),
     "ppca_mix_responsibilities_dev": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ppca_mix_component_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, c_double_p, C.POINTER(C.c_int64)]),

@@ -1312,10 +1312,14 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
     }
     HIP_TRY(launch_mix_shift(aux, nm, ctx->stream));
     ctx->stats_llk_at = -1;
+    int *used_all = reinterpret_cast<int *>(aux + 520);  // rows each component pass gathered (diagnostic: ppca_mix_last_rows_used)
     for (int c = 0; c < nm; ++c) {
+        const int *used_dev = nullptr;
         if (int rc = mix_component_enqueue(ctx, ds, models_in[c], ud ? ud + (size_t)c * n : nullptr, aux + c, pack + off[c],
-                                           pack + sums_at + c, nullptr))
+                                           pack + sums_at + c, &used_dev))
             return rc;
+        if (used_dev) HIP_TRY(hipMemcpyAsync(used_all + c, used_dev, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        else HIP_TRY(hipMemsetAsync(used_all + c, 0xFF, sizeof(int), ctx->stream));  // (-1: the pass took every row)
     }
     if (comm) {
         if (int rc = ppca_comm_allreduce(comm, pack, total, 0)) return rc;
@@ -1325,9 +1329,21 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
     HIP_TRY(launch_mix_logweights(pack + sums_at, aux, pack + llk_at, nm, aux + 256, ctx->stream));
     double *hs = static_cast<double *>(ctx->hstage);
     HIP_TRY(hipMemcpyAsync(hs, aux + 256, sizeof(double) * (size_t)(nm + 1), hipMemcpyDeviceToHost, ctx->stream));
+    int *hused = reinterpret_cast<int *>(hs + 260);
+    HIP_TRY(hipMemcpyAsync(hused, used_all, sizeof(int) * (size_t)nm, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < nm; ++c) log_weights_out[c] = hs[c];
     if (llk_in) *llk_in = hs[nm];
+    ctx->mix_rows_used.assign(nm, 0);
+    for (int c = 0; c < nm; ++c) ctx->mix_rows_used[c] = hused[c] < 0 ? n : (int64_t)hused[c];
+    return PPCA_OK;
+}
+
+extern "C" int ppca_mix_last_rows_used(ppca_ctx *ctx, int64_t *rows, int32_t n_models) {
+    if (!ctx || !rows) return fail(PPCA_ERR_INVALID, "null argument");
+    USE_CTX(ctx);
+    if ((size_t)n_models != ctx->mix_rows_used.size()) return fail(PPCA_ERR_INVALID, "the last mixture step had %d components", (int)ctx->mix_rows_used.size());
+    for (int c = 0; c < n_models; ++c) rows[c] = ctx->mix_rows_used[c];
     return PPCA_OK;
 }
 

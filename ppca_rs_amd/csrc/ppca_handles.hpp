@@ -79,6 +79,7 @@ struct ppca_ctx {
     size_t mixpack_cap = 0;
     BufRef mixaux;   // ... its small device-side vectors: maxima / shifts, new log-weights + llk
     size_t mixaux_cap = 0;
+    std::vector<int64_t> mix_rows_used;  // rows of this context's shard each component pass of the last mixture step gathered
     // pinned host memory: a small staging area for asynchronous uploads / downloads of a few values, and the two chunk
     // buffers of the pipelined device-to-host copy (ppca_dataset_to_host, ppca_infer); allocated on first use
     void *hstage = nullptr;

@@ -957,6 +957,81 @@ def test_rccl_two_ranks_when_two_gpus(tmp_path):
         assert abs(a["sigma"] - b["sigma"]) < 1e-10 * a["sigma"] and _rel(b["transform"], a["transform"]) < 1e-9
 
 
+def test_group_step_two_devices_when_two_gpus(P, oracle):
+    """ppca_comm_create_all + ppca_em_step_group with n = 2: ONE host thread drives two GPUs, the two all-reduces issued as one
+    RCCL group; both devices must end on the model a single device reaches on the whole dataset.  Skipped on a 1-GPU box."""
+    import torch
+
+    from ppca_rs_amd import _lib
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    lib = _lib.lib()
+    x, _, _ = oracle.synth(6001, 256, 10, 0.3, 17)
+    rng = np.random.default_rng(4)
+    start = P.PPCAModel(1.0, rng.standard_normal((256, 10)), np.zeros(256))
+    ctx0 = _lib.default_context()
+    want, want_llk = start.iterate_with_llk(P.Dataset(x))
+    ctxs = [_lib.Context(0), _lib.Context(1)]
+    half = (len(x) + 1) // 2  # the rule of Dataset.chunks (src/python_bindings.rs:110-118)
+    shards = [P.Dataset(x[:half], ctx=ctxs[0]), P.Dataset(x[half:], ctx=ctxs[1])]
+    comms = (C.c_void_p * 2)()
+    _lib.check(lib.ppca_comm_create_all((C.c_void_p * 2)(ctxs[0].handle, ctxs[1].handle), 2, comms))
+    assert lib.ppca_comm_n_ranks(comms[0]) == 2 and lib.ppca_comm_rank(comms[1]) == 1
+    outs = []
+    for c in ctxs:
+        h = C.c_void_p()
+        _lib.check(lib.ppca_model_alloc(c.handle, 256, 10, C.byref(h)))
+        outs.append(h)
+    llk = C.c_double(0.0)
+    start1 = P.PPCAModel(1.0, start.transform, start.mean)  # (a model object caches ONE device copy)
+    ins = [start._device(ctxs[0]), start1._device(ctxs[1])]
+    _lib.check(lib.ppca_em_step_group(comms, 2, (C.c_void_p * 2)(shards[0]._h, shards[1]._h), (C.c_void_p * 2)(ins[0].h, ins[1].h),
+                                      None, (C.c_void_p * 2)(*outs), C.byref(llk)))
+    assert abs(llk.value - want_llk) < 1e-11 * abs(want_llk)
+    got = []
+    for h in outs:
+        sig, cc, mm = C.c_double(0.0), np.empty((256, 10)), np.empty(256)
+        _lib.check(lib.ppca_model_download(h, C.byref(sig), _lib.ptr(cc), _lib.ptr(mm)))
+        got.append((sig.value, cc, mm))
+        lib.ppca_model_free(h)
+    assert got[0][0] == got[1][0]
+    np.testing.assert_array_equal(got[0][1], got[1][1])  # identical finalisation on both devices, no broadcast
+    np.testing.assert_array_equal(got[0][2], got[1][2])
+    assert abs(got[0][0] - want.isotropic_noise) < 1e-10 * want.isotropic_noise and _rel(got[0][1], want.transform) < 1e-9
+    for i in range(2):
+        lib.ppca_comm_destroy(comms[i])
+    del ctx0
+
+
+def test_sharded_mixture_over_rccl_when_two_gpus():
+    """BASELINE config 5's step over two row shards with BOTH of its collectives inside the library
+    (ppca_mix_em_step_sharded: all-reduce(MAX) of the component maxima, all-reduce(SUM) of [K statistics | K sums | llk]):
+    bench.py --config 5 --gpus 2 must trace the log-likelihoods of the one-GPU run.  Skipped on a 1-GPU box."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    traces = []
+    for gpus in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "5", "--gpus", str(gpus), "--samples", "400000",
+                            "--components", "4", "--steps", "3", "--warmup", "3", "--no-cpu"] + (["--collective", "capi"] if gpus > 1 else []),
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["n_gpus"] == gpus
+        if gpus > 1:
+            assert "ppca_mix_em_step_sharded" in j["config"]["collective"]
+        traces.append(np.array(j["llk_per_sample_trace"]))
+    assert _rel(traces[1], traces[0]) < 1e-9
+
+
 def test_concurrent_calls_on_one_context(P, oracle):
     """The reference's methods release the GIL (src/python_bindings.rs:466-511) and may be called from several
     threads; ctypes drops the GIL too, so four threads hammer ONE context with different models (llk, iterate,
