@@ -320,6 +320,14 @@ int ppca_debug_counters(ppca_ctx *ctx, int64_t *out8, int32_t reset);
  * computes C_o^T C_o in f64 (output_covariance.rs:57-70).  Synchronises. */
 int ppca_gram_engine(ppca_ctx *ctx, const ppca_model *model, int32_t *engine);
 
+/* Which guards of the most recent EM pass of the fused path (d <= 256, k <= 10) on this context sent it to the fp64 engine:
+ * *gram_unsafe -- the model tripped the dynamic-range guard of the int8-sliced Gram (see ppca_gram_engine);
+ * *stats_unsafe -- the reduced statistics were not large against the rounding of the fixed-point form of the mask-side
+ * contraction S / U / totals (a sample far above its neighbours, e.g. an outlier row, lifts its workgroup's column
+ * exponents; dimensions masked in that sample then sum coarsely cut rows): the pass was repeated with fp64 accumulation,
+ * as the reference sums (ppca_model.rs:297-306).  Both decided on the device; this call synchronises. */
+int ppca_em_last_guard(ppca_ctx *ctx, int32_t *gram_unsafe, int32_t *stats_unsafe);
+
 /* One v_mfma_f64_16x16x4_f64 on host-supplied A (16 x 4) and B (4 x 16), result
  * (16 x 16) written through the C/D lane map the kernels assume (unit test). */
 int ppca_debug_mfma_probe(ppca_ctx *ctx, const double *a16x4, const double *b4x16, double *out16x16);

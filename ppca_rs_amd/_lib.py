@@ -121,6 +121,7 @@ SIGNATURES = {
     "ppca_em_step_group": (C.c_int, [c_void_pp, C.c_int32, c_void_pp, c_void_pp, C.POINTER(Prior), c_void_pp, c_double_p]),
     "ppca_ctx_set_grid_limit": (C.c_int, [C.c_void_p, C.c_int32]),
     "ppca_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    "ppca_em_last_guard": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "ppca_gram_engine": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p]),
     "ppca_debug_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppca_debug_mfma_i8_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -220,6 +221,12 @@ class Context:
         out = (C.c_int64 * 8)()
         check(lib().ppca_debug_counters(self.handle, out, int(reset)))
         return [int(v) for v in out]
+
+    def last_guard(self):
+        """ppca_em_last_guard: (gram_unsafe, stats_unsafe) of the most recent fused EM pass on this context."""
+        g, w = C.c_int32(0), C.c_int32(0)
+        check(lib().ppca_em_last_guard(self.handle, C.byref(g), C.byref(w)))
+        return int(g.value), int(w.value)
 
     def enable_timing(self, on: bool) -> None:
         check(lib().ppca_ctx_enable_timing(self.handle, int(on)))

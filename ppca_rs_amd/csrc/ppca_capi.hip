@@ -736,6 +736,8 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
     a.no_llk = ctx->skip_llk;
     if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
     fused_qtab_layout(ctx->qtab->p, a);
+    if (int rc = ensure(ctx->errb, ctx->errb_cap, sizeof(double) * (size_t)grid * W_GUARD_NCOL)) return rc;
+    a.errb = static_cast<double *>(ctx->errb->p);
 #ifdef PPCA_PHASE_TIMING
     BufRef dbg;  // [grid][16] phase sums of one thread per role, then [grid][8 waves][16] per-wave sums (em8_kernel)
     if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 144, &dbg)) return rc;
@@ -754,6 +756,14 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
         ctx->events.emplace_back(e0, e1);
     }
     HIP_TRY(launch_reduce_partials(a.part, grid, L.len, stats_dev, ctx->stream));
+    {
+        // second stage: the device decides whether the pass is repeated on the fp64 engine (the model tripped the Gram guard,
+        // or the reduced statistics are not large against the rounding of the int8 form of the mask-side contraction);
+        // three launches that return at once otherwise
+        const int *runflag = nullptr;
+        HIP_TRY(launch_em_wguard(model->k, grid, a, stats_dev, ctx->stream, &runflag));
+        if (runflag) HIP_TRY(launch_reduce_partials(a.part, grid, L.len, stats_dev, ctx->stream, 0, runflag));
+    }
 #ifdef PPCA_PHASE_TIMING
     {
         std::vector<double> h((size_t)grid * 144);
@@ -1476,6 +1486,21 @@ extern "C" int ppca_ctx_set_grid_limit(ppca_ctx *ctx, int32_t n_workgroups) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "null context");
     USE_CTX(ctx);
     ctx->n_cu = (n_workgroups > 0 && n_workgroups < ctx->n_cu_device) ? n_workgroups : ctx->n_cu_device;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_em_last_guard(ppca_ctx *ctx, int32_t *gram_unsafe, int32_t *stats_unsafe) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "null context");
+    USE_CTX(ctx);
+    int flags[16] = {0};
+    if (ctx->qtab) {
+        PassArgs a{};
+        fused_qtab_layout(ctx->qtab->p, a);
+        HIP_TRY(hipMemcpyAsync(flags, a.qflag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (gram_unsafe) *gram_unsafe = (flags[0] | flags[1] | flags[2] | flags[3]) ? 1 : 0;
+    if (stats_unsafe) *stats_unsafe = flags[9];
     return PPCA_OK;
 }
 

@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // ===================================================================== mask-side statistics
 // Diagnostic counters as in ppca_em8.hip: [0] rescales beyond a workgroup's first, [1] periodic flushes, [2] the largest
-// number of tiles one workgroup walked, [3] launches.
+// number of tiles one workgroup walked, [3] workgroups whose statistics were recomputed in fp64 (rounding check).
 __device__ unsigned long long e16_counters[4];
 
 template <int K>
@@ -953,6 +953,9 @@ __global__ __launch_bounds__(512) void sstat16_kernel(S16Args p) {
     unsigned attempt = 0u;
     int pending = 0, have_scale = 0, flushed = 0, groups = 0;
     int n_rescale = 0, n_flush = 0;  // (wave-uniform: diagnostic counters)
+    int rows_win = 0;                // rows cut since the last flush (the window the rounding check of emit() speaks about)
+    unsigned *wbad = vstamp + 1;     // set when a flush window's sums are not large against the rounding of the cut
+    if (tid == 0) *wbad = 0u;
     StatsLayout L(d, K);
     double *out = p.part + (int64_t)blockIdx.x * L.len;
 
@@ -1072,6 +1075,34 @@ __global__ __launch_bounds__(512) void sstat16_kernel(S16Args p) {
     auto emit = [&](int lane, bool accumulate, bool clear) {
         asm volatile("" : "+v"(lane));
         const int l15 = lane & 15, l4 = lane >> 4;
+        // The rounding check of this flush window (the guard of the fixed-point form; em8_kernel's is global, behind
+        // wguard_kernel -- here it is per workgroup and window, conservative): a row far above its neighbours lifts the column
+        // exponents, and a dimension masked in that row sums rows cut far below their resolution.  A diagonal column of S
+        // (non-negative terms) of a dimension observed in the window must hold at least 2^34 x the rounding bound
+        // 4 sqrt(rows) quanta; otherwise the workgroup's statistics are recomputed in fp64 by sstat16_fallback_kernel.
+        if (have_scale && rows_win > 0) {
+            constexpr int tW = (KP + K) >> 4, lW = (KP + K) & 15;  // where the window's totals (column w) sit
+            const double thr = __builtin_sqrt((double)rows_win) * 0x1p36;
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long seen = __builtin_amdgcn_ballot_w64(accM[r][tW][q] != 0ll);
+                    const bool observed = (seen >> ((lane & 48) | lW)) & 1ull;
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) {
+                        const int c = 16 * t + l15;
+                        bool diag = false;
+#pragma unroll
+                        for (int a = 0; a < K; ++a) diag = diag || (c == tri(a, a));
+                        const double mag = __builtin_fabs((double)accM[r][t][q]);
+                        bad = bad || (diag && observed && Ex[c] <= 5000 && mag < thr);
+                    }
+                }
+            if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) *wbad = 1u;
+        }
+        rows_win = 0;
 #pragma unroll
         for (int t = 0; t < NCT; ++t) {
             const int c = 16 * t + l15, a = c - KP;
@@ -1178,6 +1209,7 @@ __global__ __launch_bounds__(512) void sstat16_kernel(S16Args p) {
                 ++groups;
             }
             pending = (!viol && !con) ? 1 : 0;
+            if (!viol) rows_win += B;
             if (viol ? have_scale != 0 : groups >= E16_FLUSH_GROUPS) {
                 emit(lane, flushed != 0, true);
                 flushed = 1;
@@ -1195,11 +1227,78 @@ __global__ __launch_bounds__(512) void sstat16_kernel(S16Args p) {
         __syncthreads();
     }
     emit(lane_entry, flushed != 0, false);
+    __syncthreads();
     if (tid == 0) {
+        out[L.scalars + 7] = *wbad ? 1.0 : 0.0;  // read and cleared by sstat16_fallback_kernel (the next launch)
+        if (*wbad) atomicAdd(&e16_counters[3], 1ull);
         if (n_rescale) atomicAdd(&e16_counters[0], (unsigned long long)n_rescale);
         if (n_flush) atomicAdd(&e16_counters[1], (unsigned long long)n_flush);
         atomicMax(&e16_counters[2], (unsigned long long)(tile_end > tile_begin ? tile_end - tile_begin : 0));
-        if (blockIdx.x == 0) atomicAdd(&e16_counters[3], 1ull);
+    }
+}
+
+// The fp64 form of sstat16_kernel for the workgroups whose rounding check failed (cold path): S, U, totals of the
+// workgroup's tiles summed sample by sample in fp64 from the handed-over rows and the per-tile sample masks, as the
+// reference sums them (ppca_model.rs:297-306, :338-348).  Thread = (dimension, column parity); a tile's rows go through
+// LDS.  Every workgroup reads its flag (slot 7 of its partial's scalars) and clears it; unflagged ones return at once.
+template <int K>
+__global__ __launch_bounds__(256) void sstat16_fallback_kernel(S16Args p) {
+    using cfg = Cfg16<K>;
+    constexpr int KP = cfg::KP, B = cfg::B, NC = cfg::NC, NCOL = cfg::NCOL;
+    __shared__ double rows[B * NCOL];
+    __shared__ int flag;
+    const int tid = threadIdx.x, d = p.d;
+    StatsLayout L(d, K);
+    double *out = p.part + (int64_t)blockIdx.x * L.len;
+    if (tid == 0) {
+        flag = out[L.scalars + 7] != 0.0;
+        out[L.scalars + 7] = 0.0;
+    }
+    __syncthreads();
+    if (!flag) return;
+    const int64_t n = p.n;
+    const int64_t ntiles = (n + B - 1) / B;
+    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+    const int dim = tid;  // thread = dimension (one wave per SIMD); the columns in two sweeps over the tiles, NU running sums each
+    constexpr int NU = (NC + 1) / 2;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        double acc[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc[u] = 0.0;
+        for (int64_t t = tile_begin; t < tile_end; ++t) {
+            const int64_t left = n - t * B;
+            const int nr = (int)(left < B ? left : B);
+            __syncthreads();
+            for (int idx = tid; idx < nr * NCOL; idx += 256) rows[idx] = p.Wrows[t * B * NCOL + idx];
+            __syncthreads();
+            const unsigned mb = p.Mb[t * 256 + dim];  // byte w = rows 8 w .. 8 w + 7 of the tile, row r at bit 7 - r
+#pragma unroll 1
+            for (int i = 0; i < nr; ++i) {
+                const bool on = (mb >> (8 * (i >> 3) + 7 - (i & 7))) & 1u;
+                const double *ri = rows + i * NCOL + half * NU;  // (NCOL >= 2 NU: columns past NC are zeros of the hand-over rows)
+                static_for<(NU + 15) / 16>([&](auto blk_tag) {  // (sixteen columns at a time: the fence keeps the loads of a row from
+                    constexpr int u0 = 16 * decltype(blk_tag)::value;  //  all being hoisted into registers at once)
+#pragma unroll
+                    for (int u = u0; u < (u0 + 16 < NU ? u0 + 16 : NU); ++u) acc[u] += on ? ri[u] : 0.0;  // select, never multiply
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        }
+        if (dim < d) {
+#pragma unroll 1
+            for (int u = 0; u < NU; ++u) {
+                const int c = half * NU + u, a = c - KP;
+                if (c >= NC) break;
+                double *dst = c < KP ? out + L.S + (int64_t)dim * KP + c : (a < K ? out + L.U + (int64_t)dim * K + a : out + L.totals + dim);
+                double v = 0.0;
+#pragma unroll
+                for (int w = 0; w < NU; ++w) v = (w == u) ? acc[w] : v;  // (register arrays are indexed by compile-time constants only)
+                *dst = v;
+            }
+        }
     }
 }
 
@@ -1249,6 +1348,8 @@ static hipError_t launch_em16_t(int grid, const Em16Launch &a, hipStream_t s) {
     b.Wrows = a.Wrows; b.Mb = a.Mb; b.n = a.n; b.d = a.d; b.part = a.part;
     if (hipError_t er = set_lds_once(&sstat16_kernel<K>, lds_s, done_s); er != hipSuccess) return er;
     hipLaunchKernelGGL((sstat16_kernel<K>), dim3(grid), dim3(512), lds_s, s, b);
+    if (hipError_t er = hipGetLastError(); er != hipSuccess) return er;
+    hipLaunchKernelGGL((sstat16_fallback_kernel<K>), dim3(grid), dim3(256), 0, s, b);  // (returns at once unless the check failed)
     return hipGetLastError();
 }
 

@@ -106,7 +106,8 @@ struct Cfg8 {
     static constexpr int OFF_BAR = OFF_E + NCOL / 2 + 4;  // counters: front barrier, back barrier, tiles digitised, violation stamp
     static constexpr int OFF_MU = OFF_BAR + 4;            // the mean (DP doubles, zero past d): re-read by the staging of every tile
     static constexpr int OFF_K = OFF_MU + DP;             // model scalars: sigma^2, 1 / sigma^2, ln sigma (re-read per tile)
-    static constexpr int LDS_DOUBLES = OFF_K + 4;
+    static constexpr int OFF_EB = OFF_K + 4;              // rounding bounds of the cut, per column (wguard_kernel)
+    static constexpr int LDS_DOUBLES = OFF_EB + NCOL;
     static_assert(NCOL / 2 <= 64, "one back wave digitises NCOL / 2 (column, chunk) items");
     static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget");
 };
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     for (int idx = tid; idx < B * GS; idx += 512) Gs[idx] = 1.0;  // (something finite for the back role to cut)
 #endif
     if (tid < 8) ctr[tid] = 0u;
+    if (tid < NCOL) sm[cfg::OFF_EB + tid] = 0.0;
     if (tid == 0) {
         sm[cfg::OFF_K] = s2_k;
         sm[cfg::OFF_K + 1] = 1.0 / s2_k;
@@ -260,6 +262,10 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
         int pending = 0;         // 1: the previous tile's planes wait in P0 for their partner
         int have_scale = 0, flushed = 0, groups = 0;
         int n_rescale = 0, n_flush = 0;  // (wave-uniform: diagnostic counters)
+        // Rounding bound of the cut, per column this lane covers (c = 16 t + l15), for wguard_kernel (ppca_kernels.hip): every
+        // flush window adds 4 sqrt(rows of the window) quanta 2^(E_c - F) of the exponents it was cut under.
+        double *ebs = sm + cfg::OFF_EB;  // (in LDS: touched at flushes only, by the role's first wave)
+        int rows_win = 0;
         unsigned char *smb = reinterpret_cast<unsigned char *>(sm);
         constexpr int P0_BYTES = cfg::OFF_P0 * 8, PG_BYTES = cfg::OFF_P1 * 8;
         StatsLayout L(d, K);
@@ -360,10 +366,15 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
         auto emit = [&](int lane, bool accumulate, bool clear) {
             asm volatile("" : "+v"(lane));
             const int l15 = lane & 15, l4 = lane >> 4;
+            const double win = 4.0 * __builtin_sqrt((double)rows_win);
+            rows_win = 0;
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
                 const int c = 16 * t + l15, a = c - KP;
                 const int E = have_scale ? Ex[c] : 0;
+#ifndef E8_NO_ERRB  // (A/B builds)
+                if (wave == 0 && l4 == 0 && have_scale && E <= 5000) ebs[c] += win * __hiloint2double((1023 + E - E8_F) << 20, 0);
+#endif
                 const double fsc = __hiloint2double(E > 5000 ? 0x7FF80000 : (1023 + E - E8_F) << 20, 0);
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
@@ -486,6 +497,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 // for the partial, the exponents rise and the tile is cut again.
                 if (!viol) {  // every back wave has read the tile's rows for the last time: the front may overwrite them
                     if (lane_entry == 0) __hip_atomic_fetch_add(digdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    rows_win += B;
                 }
                 const bool con = pending || (!viol && last);
                 if (con) {
@@ -514,6 +526,10 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             E8_STAMP(7)
         }
         emit(lane_entry, flushed != 0, false);
+        if (p.errb && wave == 0 && lane_entry < 16) {
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) p.errb[(int64_t)blockIdx.x * W_GUARD_NCOL + 16 * t + lane_entry] = ebs[16 * t + lane_entry];
+        }
         if (tid == 256) {
             if (n_rescale) atomicAdd(&e8_counters[0], (unsigned long long)n_rescale);
             if (n_flush) atomicAdd(&e8_counters[1], (unsigned long long)n_flush);

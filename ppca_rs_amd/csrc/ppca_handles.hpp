@@ -69,6 +69,8 @@ struct ppca_ctx {
     BufRef work;  // 2048 doubles for reductions
     BufRef qtab;  // int8 Gram slice table + scales + guard flags of the model being processed
     size_t qtab_cap = 0;
+    BufRef errb;  // [grid][W_GUARD_NCOL] rounding bounds of the int8 mask-side statistics (wguard_kernel)
+    size_t errb_cap = 0;
     BufRef gws;   // workspace of the generic split pipeline
     size_t gws_cap = 0;
     // mixture scratch, kept across iterations (hipMalloc / hipFree of hundreds of MB per component cost more than

@@ -46,7 +46,13 @@ struct PassArgs {
     int no_llk;           // EM mode: the caller does not read SC_LLK (mixture component steps): skip the
                           // per-sample logarithm of the weighted path
     double *dbg;          // diagnostic builds (-DPPCA_PHASE_TIMING): [grid][4] phase cycle sums
+    // EM mode, the guard of the int8 form of the mask-side statistics (launch_em_wguard):
+    double *errb;         // [grid][W_GUARD_NCOL]: per workgroup and column of [wP | wz | w], a bound of the rounding the fixed-point
+                          // cut added to any sum of that column (written by em8_kernel; nullptr: not collected)
+    const int *runflag;   // nullable: the fp64 instantiation of pass_kernel runs iff *runflag != 0 (set by wguard_kernel from the
+                          // Gram flags and the W-side check); nullptr: qflag decides as before
 };
+constexpr int W_GUARD_NCOL = 80;  // 16 x ceil((k' + k + 1) / 16) at k = 10
 
 // Number of workgroups the fused pass wants for n rows on a device with n_cu CUs.
 int fused_grid(int64_t n, int n_cu);
@@ -95,7 +101,14 @@ hipError_t launch_em16(int k, int grid, const Em16Launch &a, hipStream_t s);
 // The log-likelihood sweep alone (ppca_llk.hip): per-sample llks (nullable) and the per-workgroup scalars; honours
 // a.qflag like the int8 instantiation of pass_kernel.
 hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s);
-hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s, int accumulate = 0);
+hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s, int accumulate = 0,
+                                  const int *run_if = nullptr);  // run_if: device flag; the kernel returns at once when it is 0
+// Second stage of a guarded EM pass, after the partials of launch_pass_em were reduced into `stats`: wguard_kernel decides
+// on the device whether the pass must be repeated on the fp64 engine (the Gram guard's flags, or the statistics' own
+// check: a diagonal entry of S that is not large against the rounding bound of its column), and the fp64 instantiation of
+// the pass runs behind that flag.  *runflag_out: the device flag the caller hands to the second launch_reduce_partials
+// (nullptr when the stage does not apply: an engine pinned by the environment, kernel-tuning builds).
+hipError_t launch_em_wguard(int k, int grid, PassArgs a, const double *stats, hipStream_t s, const int **runflag_out);
 hipError_t launch_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
                            int has_ig, double alpha, double beta, hipStream_t s);
 hipError_t launch_synth(const double *c_dev, const double *mean_dev, double *z_work, double *x_out, int64_t row_offset,

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     }
     __syncthreads();
     if (j == 0) qflag[t] = bad;
+    if (j == 0 && t == 0) qflag[8] = qflag[9] = 0;  // the pass's run-again flag and the W-side verdict (wguard_kernel)
     const int lane = j & 63, kc = j >> 6;
     const int c = 16 * t + (lane & 15);
     int a = 0;
@@ -219,7 +220,9 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
     double *xxs = sm + cfg::OFF_S;
 
-    if (p.qflag) {  // Gram engine chosen per model by qprep's dynamic-range guard: exactly one of the two variants runs
+    if (!GI8 && p.runflag) {  // second stage of a guarded EM pass: wguard_kernel's verdict (Gram flags or the W-side check)
+        if (*p.runflag == 0) return;
+    } else if (p.qflag) {  // Gram engine chosen per model by qprep's dynamic-range guard: exactly one of the two variants runs
         int unsafe = 0;
 #pragma unroll
         for (int t = 0; t < NTP; ++t) unsafe |= p.qflag[t];
@@ -1296,11 +1299,71 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     }
 }
 
+// ------------------------------------------------------------------ guard of the int8 mask-side statistics
+// em8_kernel cuts the rows [wP | wz | w] into a fixed-point form with ONE exponent per column and workgroup that only rises
+// (ppca_em8.hip).  A row far above its neighbours -- an outlier sample, or a heavy sample weight -- lifts the exponents of
+// its workgroup, and the rows after it are cut far below their own resolution: harmless for every sum the large row is
+// part of, but a dimension that is MASKED in the large row sums only the coarsely cut ones (measured: one row at 1e6 x
+// the others, 6 000 rows on one workgroup: S_j off by 1e-3 .. 1e-2 in those dimensions).  Whether that matters is a
+// property of the REDUCED statistic, so it is decided after the reduction: every workgroup reports, per column c, a bound
+// e_c of the rounding it added to any sum of that column (4 sqrt(rows) quanta per flush window: ~14 sigma of independent
+// roundings; rows cut to nothing show up as a small sum instead), and the pass is repeated on the fp64 engine when some
+// diagonal entry S_j,aa of an observed dimension (a sum of non-negative terms z_a^2 + Sigma_aa) is not at least 2^34 x
+// sum_workgroups e_c.  The off-diagonal and [wz | w] columns ride on that test: their rows scale with the same sample
+// magnitudes (|P_ab| <= sqrt(P_aa P_bb), z_a^2 <= P_aa).
+constexpr double WGUARD_TOL = 5.820766091346741e-11;  // 2^-34
+
+template <int K>
+__global__ __launch_bounds__(256) void wguard_kernel(const double *stats, const double *errb, int grid, int d, int *qflag) {
+    constexpr int KP = Cfg<K>::KP, NTP = Cfg<K>::NTP;
+    __shared__ double es[W_GUARD_NCOL];
+    __shared__ double part3[3][W_GUARD_NCOL];
+    const int t = threadIdx.x;
+    if (t < 3 * W_GUARD_NCOL) {  // column t % 80, every third workgroup from t / 80: three independent chains per column
+        const int c = t % W_GUARD_NCOL, s0 = t / W_GUARD_NCOL;
+        double v0 = 0.0, v1 = 0.0;
+        if (errb) {
+            int b = s0;
+            for (; b + 3 < grid; b += 6) {
+                v0 += errb[(int64_t)b * W_GUARD_NCOL + c];
+                v1 += errb[(int64_t)(b + 3) * W_GUARD_NCOL + c];
+            }
+            if (b < grid) v0 += errb[(int64_t)b * W_GUARD_NCOL + c];
+        }
+        part3[s0][c] = v0 + v1;
+    }
+    __syncthreads();
+    if (t < W_GUARD_NCOL) es[t] = (part3[0][t] + part3[1][t]) + part3[2][t];
+    __syncthreads();
+    int unsafe = 0;
+    if (errb && t < d) {
+        const StatsLayout L(d, K);
+        const double tot = stats[L.totals + t];
+        if (tot != 0.0) {
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+                const double S = stats[L.S + (int64_t)t * KP + tri(a, a)];
+                if (fabs(S) * WGUARD_TOL < es[tri(a, a)]) unsafe = 1;  // (a NaN statistic compares false: it propagates as through fp64)
+            }
+        }
+    }
+    unsafe = __syncthreads_or(unsafe);
+    if (t == 0) {
+        int gram = 0;
+#pragma unroll
+        for (int u = 0; u < NTP; ++u) gram |= qflag[u];
+        qflag[8] = (gram | unsafe) ? 1 : 0;
+        qflag[9] = unsafe ? 1 : 0;
+    }
+}
+
+
 // out[e] = sum over workgroup partials in a fixed order (deterministic): four threads per element
 // each sum a contiguous quarter of the partials, the quarters are combined as (q0 + q1) + (q2 + q3).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *part, int grid_parts, int64_t len,
-                                                             double *out, int accumulate) {
+                                                             double *out, int accumulate, const int *run_if) {
     __shared__ double red[4][64];
+    if (run_if && *run_if == 0) return;
     const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int64_t e = (int64_t)blockIdx.x * 64 + l;
     const int per = (grid_parts + 3) / 4;
@@ -1705,6 +1768,7 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
     return hipErrorInvalidValue;
 #else
     if (hipError_t e = int8_pass(a); e != hipSuccess) return e;
+    if constexpr (EM) return hipSuccess;  // the fp64 variant of an EM pass runs behind launch_em_wguard, after the reduction
     return launch_pass_t<K, EM, 4, false>(grid, a, s);
 #endif
 }
@@ -1739,6 +1803,23 @@ hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
     PPCA_DISPATCH_K(k, return (launch_pass_guarded<KK, true>(grid, a, s)));
     return hipErrorInvalidValue;
 }
+hipError_t launch_em_wguard(int k, int grid, PassArgs a, const double *stats, hipStream_t s, const int **runflag_out) {
+    *runflag_out = nullptr;
+#ifdef PPCA_DEV_K10
+    return hipSuccess;  // kernel-tuning builds instantiate the int8 variants only
+#else
+    if (gram_mode() != 0) return hipSuccess;  // engine pinned: nothing to decide
+    const double *errb = (em8_enabled() && em8_covers(k)) ? a.errb : nullptr;  // (only em8_kernel cuts its rows)
+    a.runflag = a.qflag + 8;
+    *runflag_out = a.runflag;
+    PPCA_DISPATCH_K(k, {
+        hipLaunchKernelGGL((wguard_kernel<KK>), dim3(1), dim3(256), 0, s, stats, errb, grid, a.d, a.qflag);
+        return (launch_pass_t<KK, true, 4, false>(grid, a, s));
+    });
+    return hipErrorInvalidValue;
+#endif
+}
+
 hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s) {
     PPCA_DISPATCH_K(k, return (launch_pass_guarded<KK, false>(grid, a, s)));
     return hipErrorInvalidValue;
@@ -1772,9 +1853,10 @@ hipError_t launch_qprep16(int k, const double *model, int d, double *qscale, sig
 }
 int fused_gram_tiles(int k) { return (k * (k + 1) / 2 + 15) / 16; }
 
-hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s, int accumulate) {
+hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s, int accumulate,
+                                  const int *run_if) {
     int blocks = (int)((len + 63) / 64);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, part, grid_parts, len, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, part, grid_parts, len, out, accumulate, run_if);
     return hipGetLastError();
 }
 

@@ -101,6 +101,7 @@ def test_eight_wave_em_pass_steady_state(P, oracle, ctx, k, d):
             got = _stats(P, P.Dataset(x, weights), m)
             cnt = ctx.debug_counters()
             assert cnt[2] >= (n // 32) // cap and cnt[1] >= 1, cnt  # tiles walked by one workgroup; periodic flushes
+            assert ctx.last_guard() == (0, 0)  # (the int8 engine on both sides: neither guard sent the pass to fp64)
             _assert_stats(got, oracle.stats(x, s, c, mu, weights), d, k, 1e-9, (k, cap, weights is None))
         if cap == 2:
             # gathered: a third of the rows dropped (weight exactly 0), the others with weights over 20 binary orders
@@ -165,7 +166,7 @@ def test_two_kernel_em_pass_steady_state(P, oracle, ctx, k, d):
             ctx.debug_counters(reset=True)
             got = _stats(P, P.Dataset(x, weights), m)
             cnt = ctx.debug_counters()
-            assert cnt[6] >= (n // 32) // cap and cnt[5] >= 1, cnt
+            assert cnt[6] >= (n // 32) // cap and cnt[5] >= 1 and cnt[7] == 0, cnt  # (no workgroup needed the fp64 statistics)
             _assert_stats(got, oracle.stats(x, s, c, mu, weights), d, k, 1e-9, (k, cap, weights is None))
     ctx.set_grid_limit(2)
     ds = P.Dataset(x, w)
@@ -298,3 +299,39 @@ def test_sharded_mixture_hands_out_detached_models(P, ctx):
     for m, c in zip(mid.models, host):
         np.testing.assert_array_equal(m.transform, c)
     assert em.mixture().llk(ds) > before
+
+
+@pytest.mark.parametrize("k,d", [(10, 256), (4, 64), (16, 200), (12, 64)])
+def test_outlier_row_sends_the_statistics_to_fp64(P, oracle, ctx, k, d):
+    """One row at 1e6 x the others lifts the column exponents of its workgroup's fixed-point form; the dimensions MASKED in
+    that row then sum rows cut far below their own resolution (measured before the guard: S_j off by 4e-5 on the full
+    grid, 1e-3 .. 1e-2 on one workgroup).  wguard_kernel sees it in the reduced statistics (a diagonal entry of S not
+    large against the rounding bound of its column) and the pass is repeated with fp64 accumulation, as the reference sums
+    (ppca_model.rs:297-306): every block within 1e-9 of the oracle, dimension by dimension where the large row is masked;
+    the same data without the outlier stays on the int8 engine."""
+    n = 6000
+    rng = np.random.default_rng(3)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 11)
+    c, mu, s = 0.5 * rng.standard_normal((d, k)), np.zeros(d), 0.7
+    m = P.PPCAModel(s, c, mu)
+    kp = k * (k + 1) // 2
+    diag = [a * (a + 1) // 2 + a for a in range(k)]
+    for cap in (0, 1):
+        ctx.set_grid_limit(cap)
+        ctx.debug_counters(reset=True)
+        _assert_stats(_stats(P, P.Dataset(x), m), oracle.stats(x, s, c, mu), d, k, 1e-9, (k, cap, "clean"))
+        # k <= 10: the global check behind wguard_kernel; k = 11..16: sstat16_kernel's per-workgroup check (counter 7)
+        assert (ctx.last_guard() == (0, 0)) if k <= 10 else (ctx.debug_counters()[7] == 0)
+        xo = x.copy()
+        xo[100] *= 1e6
+        got, want = _stats(P, P.Dataset(xo), m), oracle.stats(xo, s, c, mu)
+        assert (ctx.last_guard() == (0, 1)) if k <= 10 else (ctx.debug_counters()[7] >= 1), cap
+        _assert_stats(got, want, d, k, 1e-9, (k, cap, "outlier"))
+        Sg, Sw = got[d * k:d * k + d * kp].reshape(d, kp), want[d * k:d * k + d * kp].reshape(d, kp)
+        masked = ~np.isfinite(xo[100])
+        assert masked.any() and (np.abs(Sg[masked][:, diag] - Sw[masked][:, diag]) / np.abs(Sw[masked][:, diag])).max() < 1e-9
+        # (an EM step from here solves row systems of condition ~1e12 -- the outlier dominates every S_j it is observed in --,
+        #  so 1e-9 in the statistics is all two fp64 implementations can agree to; the noise level, a plain sum, still does)
+        s1, _, _ = oracle.iterate(xo, s, c, mu)
+        new = m.iterate(P.Dataset(xo))
+        assert abs(new.isotropic_noise - s1) < 1e-9 * s1 and np.isfinite(new.transform).all()
