@@ -540,6 +540,9 @@ def main() -> None:
             "samples_per_sec": n * iters_per_s,
             "llk_per_sample_last_input_model": llk_last / n,
             "gram_engine": gram_engine,
+            # the two device-side guards of the LAST EM pass of the timed region: did the model send the pass to the fp64 Gram,
+            # did the reduced statistics send it to the fp64 mask-side contraction (ppca_em_last_guard; fused shapes only)
+            "guards_last_pass": dict(zip(("gram_unsafe", "stats_unsafe"), ctx.last_guard())) if fused else None,
             # the bound is max(bytes / HBM peak, flops / fp64 peak) per sample; at d = 256,
             # k = 10 that is the fp64 pipe (0.687 ns vs 0.261 ns), so the headline fraction is the fp64 one
             # and the HBM figures ride along.

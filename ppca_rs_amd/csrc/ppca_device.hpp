@@ -220,6 +220,35 @@ __device__ __forceinline__ void mfma_i8_x1(const i4_t &a, const i4_t &b0, i4_t &
         : "v"(a), "v"(b0));
 }
 
+// ln(x) for a positive normal x with its polynomial constants read from constant memory at the point of use (scalar loads
+// into SGPRs).  The library logarithm's constants are materialised in vector registers and hoisted out of the tile loop;
+// under the register pressure of an eight-wave kernel they were what the allocator spilled (llk8_kernel: seven doubles
+// reloaded from scratch inside the solver step, each reload waiting on the row loads in flight).  Method: x = f 2^e,
+// f in [sqrt(1/2), sqrt(2)); s = (f - 1) / (f + 1), ln f = 2 s (1 + s^2/3 + s^4/5 + ...): s^2 <= 0.0295, ten terms leave
+// < 1e-17 relative.
+__constant__ double LEAN_LOG_C[10] = {1.0 / 3.0,  1.0 / 5.0,  1.0 / 7.0,  1.0 / 9.0,  1.0 / 11.0,
+                                      1.0 / 13.0, 1.0 / 15.0, 1.0 / 17.0, 1.0 / 19.0, 1.0 / 21.0};
+__device__ __forceinline__ double lean_log(double x) {
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double f = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    const bool low = f < 0.7071067811865476;
+    f = low ? f + f : f;
+    e = low ? e - 1 : e;
+    const double den = f + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    const double num = f - 1.0;
+    double s = num * r;
+    s = __builtin_fma(__builtin_fma(-den, s, num), r, s);  // one correction of the quotient
+    const double z = s * s;
+    double pz = LEAN_LOG_C[9];
+#pragma unroll
+    for (int i = 8; i >= 0; --i) pz = __builtin_fma(pz, z, LEAN_LOG_C[i]);
+    const double lf = __builtin_fma(2.0 * s * z, pz, 2.0 * s);
+    return __builtin_fma((double)e, LN_2, lf);
+}
+
 template <int K>
 constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
 

@@ -64,6 +64,12 @@ constexpr int E8_FLUSH_GROUPS = 100;
 #define E8_GS_PAD 18  // row stride of [G | b] / W rows = 16 NTP + 18 doubles: even, so that the solver's lane-per-sample accesses
                       // pair up into 16-byte LDS operations that spread over all banks (measured: 17 costs 2 %)
 #endif
+#ifndef E8_BARRIER_RTN
+#define E8_BARRIER_RTN 0  // (measured: within the run-to-run noise)
+#endif
+#ifndef E8_EARLY_DIGDONE
+#define E8_EARLY_DIGDONE 1
+#endif
 #ifndef E8_DECOUPLED
 #define E8_DECOUPLED 0  // 1: the roles meet through LDS counters only; 0: a workgroup barrier per tile after P3 (round 3)
 #endif
@@ -117,7 +123,17 @@ struct Cfg8 {
 __device__ __forceinline__ void role_barrier(unsigned *ctr, unsigned &target, int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     target += 4;
+#if E8_BARRIER_RTN
+    // the add returns the count it found: the LAST wave to arrive -- the one the others wait for -- leaves without a poll
+    unsigned found = 0u;
+    if (lane == 0) found = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((int)((unsigned)__builtin_amdgcn_readfirstlane(found) + 1u - target) >= 0) {
+        asm volatile("" ::: "memory");
+        return;
+    }
+#else
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     for (;;) {
         const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if ((int)(seen - target) >= 0) break;
@@ -691,6 +707,12 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             d4_t accb = d4_t{0, 0, 0, 0};
             const double *xrow = Xs + si * XS + DPS * kq + l4;
             const double *cpc = Cs + (DPS * kq + l4) * CS + colb;
+#if E8_EARLY_DIGDONE
+            // the count of tiles the back role has cut, requested HERE and looked at where [G | b] is stored: by then it is
+            // almost always enough, and the poll (an LDS round trip behind everything this wave has queued: ~0.7 k cycles per
+            // tile in the phase table) is skipped
+            const unsigned dd_early = __hip_atomic_load(digdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
             i4_t af[2][4];
             double v[2][4];
             // one digit pair: contract, then fold the exact integer digit sums (|sum| <= 2^14) into the running fp64
@@ -771,7 +793,10 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
             E8_FINE(0)
             // [G | b] shares its buffer with the previous tile's W rows: wait until the back role has cut them (long done:
             // the cut is the first thing the back does after the workgroup barrier)
-            wait_counter(digdone, 4u * (unsigned)rel);
+#if E8_EARLY_DIGDONE
+            if ((int)((unsigned)__builtin_amdgcn_readfirstlane(dd_early) - 4u * (unsigned)rel) < 0)
+#endif
+                wait_counter(digdone, 4u * (unsigned)rel);
             E8_FINE(1)
             if (gram_wave) {
 #pragma unroll

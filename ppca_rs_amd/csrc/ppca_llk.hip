@@ -328,8 +328,316 @@ __global__ __launch_bounds__(256) void llk2_kernel(PassArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// llk8_kernel -- the same sweep as an EIGHT-wave workgroup (two waves per SIMD, 256 registers each; round 4).  One wave per
+// SIMD issues a vector instruction every ~5-8 cycles (dependent chains, LDS waits); a second wave fills those slots.  The
+// work of a tile is split eight ways instead of four: four staged rows per wave; the int8 Gram as (packed-column tile, row
+// tile) = 4 x 2 wave units, each with ITS column tile's digit-table slice resident (128 registers, as in llk2_kernel); b = X~ C
+// as (row tile, quarter of the dimensions) = 2 x 4 units, the four K-split partials summed by the solver in a fixed order.
+// The solver step (64 samples of the round's two tiles on the 64 lanes of wave 0) is unchanged.
+template <int K>
+struct CfgL8 {
+    using c = Cfg<K>;
+    static constexpr int KP = c::KP, NTP = c::NTP, B = c::B, DP = c::DP, XS = c::XS, CS = c::CS;
+    static constexpr int GS = 16 * NTP + 16 + 1;  // [G (16 NTP) | b partial of dims 0-63 (16)], 2 B rows
+    static constexpr int BS = 17;                 // b partials of dims 64-127, 128-191, 192-255: 3 x 2 B rows
+    static constexpr int OFF_X = 0;
+    static constexpr int OFF_C = OFF_X + B * XS;
+    static constexpr int OFF_G = OFF_C + DP * CS;
+    static constexpr int OFF_B1 = OFF_G + 2 * B * GS;
+    static constexpr int OFF_M = OFF_B1 + 3 * 2 * B * BS;  // mask words of the round's two tiles, 2 B x 4 u64
+    static constexpr int OFF_XX = OFF_M + 2 * B * 4;       // |x~|^2 of the 2 B samples
+    static constexpr int OFF_MU = OFF_XX + 2 * B;          // the mean (DP doubles, zero past d): re-read by the staging of every tile
+    static constexpr int LDS_DOUBLES = OFF_MU + DP;
+    static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (llk8)");
+};
+
+// Four per-lane partial sums (one register per row of a wave's four staged rows) -> the four row totals into out[0..3]
+// (store_row_sums for four rows): halves, then 16-lane rows, then four DPP steps.
+__device__ __forceinline__ void store_row_sums4(const double (&pxx)[4], int lane, double *out) {
+    const double u0 = fold_halves(pxx[0], pxx[1]);  // lanes 0-31: row 0, lanes 32-63: row 1
+    const double u1 = fold_halves(pxx[2], pxx[3]);  // lanes 0-31: row 2, lanes 32-63: row 3
+    double v = fold_rows(u0, u1);                   // 16-lane row rho holds data row: 0 -> 0, 1 -> 2, 2 -> 1, 3 -> 3
+    v += dpp_f64<0xB1, 0xF>(v);
+    v += dpp_f64<0x4E, 0xF>(v);
+    v += dpp_f64<0x141, 0xF>(v);
+    v += dpp_f64<0x140, 0xF>(v);
+    if ((lane & 15) == 0) {
+        const int rho = lane >> 4;
+        out[2 * (rho & 1) + (rho >> 1)] = v;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
+    using cfg = CfgL8<K>;
+    constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS, BS = cfg::BS;
+    constexpr int NW = 8, RPW = B / NW, DPQ = cfg::DP / 4, STEPS = DPQ / 4;
+    static_assert(NTP <= 4 && QS == 8 && RPW == 4, "int8 Gram: (column tile, row tile) wave units, 8 digit slices; 4 rows per wave");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Xs = sm + cfg::OFF_X;
+    double *Cs = sm + cfg::OFF_C;
+    double *Gs = sm + cfg::OFF_G;
+    double *B1 = sm + cfg::OFF_B1;
+    unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
+    double *xxs = sm + cfg::OFF_XX;
+
+    if (p.qflag) {  // qprep's dynamic-range guard: pass_kernel<K, false, 4, false> runs instead
+        int unsafe = 0;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) unsafe |= p.qflag[t];
+        if (unsafe) return;
+    }
+    const int tid = threadIdx.x, lane_entry = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d = p.d;
+    const int64_t n = p.n;
+    const double *mC = p.model + MODEL_HDR;
+    const double *mMean = mC + (int64_t)d * K;
+    const double s2 = p.model[1], lnsig = p.model[2];
+    for (int idx = tid; idx < cfg::DP * CS; idx += 512) {
+        int j = idx / CS, a = idx - j * CS;
+        Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
+    }
+    for (int idx = tid; idx < cfg::DP; idx += 512) sm[cfg::OFF_MU + idx] = idx < d ? mMean[idx] : 0.0;
+
+    const int64_t ntiles = (n + B - 1) / B;
+    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+    const int64_t nleft = n - tile_begin * B;
+    const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));
+    const double *Xwg = p.X + tile_begin * B * p.ldx;
+    const int rowbytes = d * (int)sizeof(double);
+    double xr[RPW][4];
+    auto load_tile = [&](int64_t tile) {
+        const int rel0 = (int)(tile - tile_begin) * B;
+        int cnt = nrel - rel0;
+        cnt = __builtin_amdgcn_readfirstlane(cnt < 0 ? 0 : (cnt > B ? B : cnt));
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(Xwg + (int64_t)rel0 * p.ldx), 0, cnt * rowbytes, 0x00020000);
+        const int wbase = wave * RPW * rowbytes;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, wbase + r * rowbytes + 1024 * h, 0);
+                xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
+                xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
+            }
+        }
+    };
+    // wave unit of the Gram: packed-column tile ct, row tile rt; of b: row tile rtb, quarter kq of the dimensions
+    const int ct = wave & 3, rt = wave >> 2;
+    const int rtb = wave & 1, kq = wave >> 1;
+    const bool gram_wave = ct < NTP;
+    // the unit's slice of the digit table, resident (128 registers).  The solver wave cannot hold it next to the packed
+    // factor (110 registers): it drops the slice for its solver step and requests it again right after (32 loads from
+    // L2 that travel under the next staging) -- a spill through scratch would wait on the row loads in flight instead.
+    i4_t qt[QS][4];
+    auto load_table = [&]() {
+        const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
+        const int qbase = ct * QS * 4 * 1024;  // (a tile past the table reads zeros)
+#pragma unroll
+        for (int sl = 0; sl < QS; ++sl)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16, qbase + (sl * 4 + kc) * 1024, 0);
+                qt[sl][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+            }
+    };
+    load_table();
+    const double qs = gram_wave ? p.qscale[16 * ct + (lane_entry & 15)] : 0.0;
+
+    auto stage_tile = [&](int lane, int slot) {
+        // the lane's four means and limits (observed <=> |x| < lim: +inf for a real dimension, -1 past d), rebuilt per tile from
+        // the LDS copy of the mean: as loop invariants they would sit in 16 registers across the solver step
+        double mu[4], lim[4];
+        {
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            const d2_t m0 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 2 * lane);
+            const d2_t m1 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 + 2 * lane);
+            mu[0] = m0[0]; mu[1] = m0[1]; mu[2] = m1[0]; mu[3] = m1[1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lim[q] = (128 * (q >> 1) + 2 * lane + (q & 1) < d) ? __builtin_inf() : -1.0;
+        }
+        int st_wlo = 0, st_whi = 0;
+        double pxx[RPW];
+        static_for<RPW>([&](auto r_tag) {
+            constexpr int r = decltype(r_tag)::value;
+            const int ri = wave * RPW + r;
+            double xt[4];
+            static_for<4>([&](auto q_tag) {
+                constexpr int q = decltype(q_tag)::value;
+                const double v = xr[r][q];
+                const bool ob = __builtin_fabs(v) < lim[q];
+                xt[q] = ob ? v - mu[q] : 0.0;
+                writelane_mask<4 * r + q>(st_wlo, st_whi, __builtin_amdgcn_ballot_w64(ob));
+            });
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<d2_t *>(Xs + ri * XS + 2 * lane) = d2_t{xt[0], xt[1]};
+            *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 + 2 * lane) = d2_t{xt[2], xt[3]};
+            pxx[r] = xt[0] * xt[0] + xt[1] * xt[1] + xt[2] * xt[2] + xt[3] * xt[3];
+        });
+        const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
+        if (lane < 4 * RPW) Ms[(slot * B + wave * RPW) * 4 + lane] = myw;
+        store_row_sums4(pxx, lane, xxs + slot * B + wave * RPW);
+    };
+    auto contract_tile = [&](int lane, int slot) {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int colb = (l15 < K) ? l15 : K;
+        d4_t accb = d4_t{0, 0, 0, 0};
+        const double *xrow = Xs + (16 * rtb + l15) * XS + DPQ * kq + l4;
+        const double *cpc = Cs + (DPQ * kq + l4) * CS + colb;
+        unsigned long long mwd[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) mwd[kc] = Ms[(slot * B + 16 * rt + l15) * 4 + kc];
+        {
+            constexpr int CH = 4;
+            double axb[2][CH], cbb[2][CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                axb[0][u] = xrow[4 * u];
+                cbb[0][u] = cpc[4 * u * CS];
+            }
+#pragma unroll
+            for (int c = 0; c < STEPS / CH; ++c) {
+                if (c + 1 < STEPS / CH) {
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
+                        cbb[(c + 1) & 1][u] = cpc[4 * ((c + 1) * CH + u) * CS];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) accb = mfma(axb[c & 1][u], cbb[c & 1][u], accb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        i4_t af[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const unsigned bits = (unsigned)(mwd[kc] >> (16 * l4)) & 0xFFFFu;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) af[kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
+        }
+        double v[4];
+#pragma unroll
+        for (int g = 0; g < QS / 2; ++g) {
+            const int sl = QS - 2 - 2 * g;
+            i4_t ia[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ia[u] = i4_t{0, 0, 0, 0};
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[kc], qt[sl + u][kc], ia[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int part = ia[1][r] * QBASE + ia[0][r];
+                v[r] = g == 0 ? (double)part : v[r] * (double)(QBASE * QBASE) + (double)part;
+            }
+        }
+        if (gram_wave) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gs[(slot * B + 16 * rt + 4 * l4 + r) * GS + 16 * ct + l15] = v[r] * qs;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // the four K-split partials of b, summed by the solver in a fixed order
+            const int row = slot * B + 16 * rtb + l4 + 4 * r;
+            if (kq == 0) Gs[row * GS + 16 * NTP + l15] = accb[r];
+            else B1[((kq - 1) * 2 * B + row) * BS + l15] = accb[r];
+        }
+    };
+
+    double run_llk = 0.0, run_w = 0.0;
+    if (tile_begin < tile_end) load_tile(tile_begin);
+    __syncthreads();
+    for (int64_t tile = tile_begin; tile < tile_end; tile += 2) {
+        int lane = lane_entry;
+        asm volatile("" : "+v"(lane));
+        stage_tile(lane, 0);
+        load_tile(tile + 1);
+        __syncthreads();
+        contract_tile(lane, 0);
+        __syncthreads();
+        stage_tile(lane, 1);
+        load_tile(tile + 2);
+        __syncthreads();
+        contract_tile(lane, 1);
+        __syncthreads();
+        if (wave == 0) {
+            const int slot = lane >> 5, i = lane & (B - 1);
+            const int64_t t = tile + slot;
+            const int64_t row = t * B + i;
+            const bool mine = t < tile_end && row < n;
+            const double *g0 = Gs + lane * GS;
+            const double *b1 = B1 + lane * BS;
+            const double wgt = mine ? (p.w ? p.w[row] : 1.0) : 0.0;
+            const unsigned long long *mw = Ms + lane * 4;
+            const int m = __popcll(mw[0]) + __popcll(mw[1]) + __popcll(mw[2]) + __popcll(mw[3]);
+            const double xx = xxs[lane];
+            Posterior<K> post;
+            double pm;
+            int pe;
+            post.factor([&](int e) { return g0[e]; }, s2, pm, pe);
+            const double quad = post.forward_quad([&](int a) { return ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; });
+            const double lk = sample_llk(xx, quad, lean_log(pm) + (double)pe * LN_2, s2, lnsig, m, K);
+            run_llk += wgt * lk;
+            run_w += wgt;
+            if (p.llks && mine) p.llks[row] = lk;
+            __builtin_amdgcn_sched_barrier(0);
+            load_table();
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        const double v2 = wave_sum(run_llk), v3 = wave_sum(run_w);
+        if (lane_entry == 0) {
+            double *sc = p.scal_part + (int64_t)blockIdx.x * 8;
+            sc[SC_SQERR] = 0.0;
+            sc[SC_DEVSQ] = 0.0;
+            sc[SC_LLK] = v2;
+            sc[SC_SUMW] = v3;
+            sc[SC_NONEMPTY] = 0.0;
+            sc[5] = 0.0;
+            sc[6] = 0.0;
+            sc[7] = 0.0;
+        }
+    }
+}
+
+static bool llk8_enabled() {  // PPCA_LLK8=0: the four-wave llk2_kernel (A/B runs)
+    static const bool v = [] {
+        const char *e = getenv("PPCA_LLK8");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+
+template <int K>
+static hipError_t launch_llk8_t(int grid, const PassArgs &a, hipStream_t s) {
+    const size_t lds = sizeof(double) * CfgL8<K>::LDS_DOUBLES;
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&llk8_kernel<K>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((llk8_kernel<K>), dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int K>
 static hipError_t launch_llk2_t(int grid, const PassArgs &a, hipStream_t s) {
+    if (llk8_enabled()) return launch_llk8_t<K>(grid, a, s);
     const size_t lds = sizeof(double) * CfgL<K>::LDS_DOUBLES;
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
