@@ -213,26 +213,58 @@ static int d2h_pipelined(ppca_ctx *ctx, double *dst, const double *src, size_t n
             if (int rc = ensure(ctx->canon[b], ctx->canon_cap[b], CHUNK * sizeof(double))) return rc;
     const size_t nch = (n + CHUNK - 1) / CHUNK;
     unsigned hw = std::thread::hardware_concurrency();
-    int T = (int)std::min<unsigned>(12u, std::max<unsigned>(1u, hw / 2));
-    if (const char *e = getenv("PPCA_D2H_THREADS")) T = std::max(1, atoi(e));
+    int want = (int)std::min<unsigned>(12u, std::max<unsigned>(1u, hw / 2));
+    if (const char *e = getenv("PPCA_D2H_THREADS")) want = std::max(1, atoi(e));
     std::atomic<long> ready{0};
-    std::atomic<bool> failed{false};
-    std::vector<std::atomic<int>> done(nch);
-    for (auto &x : done) x.store(0);
+    std::atomic<bool> failed{false}, go{false};
+    std::atomic<int> nthreads{0};  // how many copy threads exist (set before `go`): the slices of a chunk are cut for that many
+    std::unique_ptr<std::atomic<int>[]> done;
     auto chunk_len = [&](size_t c) { return std::min(CHUNK, n - c * CHUNK); };
     std::vector<std::thread> pool;
-    for (int t = 0; t < T; ++t)
-        pool.emplace_back([&, t] {
-            for (size_t c = 0; c < nch; ++c) {
-                while (ready.load(std::memory_order_acquire) <= (long)c) {
+    // No C++ exception may cross the C-ABI: allocation and thread creation are fenced; with fewer threads than wanted the
+    // copy is cut for those that exist, with none it falls back on the plain copy.
+    try {
+        done.reset(new std::atomic<int>[nch]);
+        for (size_t c = 0; c < nch; ++c) done[c].store(0);
+        pool.reserve((size_t)want);
+        for (int t = 0; t < want; ++t)
+            pool.emplace_back([&, t] {
+                while (!go.load(std::memory_order_acquire)) {
                     if (failed.load()) return;
                     std::this_thread::yield();
                 }
-                const size_t len = chunk_len(c), per = (len + T - 1) / T, a = std::min(len, per * t), b = std::min(len, a + per);
-                if (b > a) std::memcpy(dst + c * CHUNK + a, static_cast<const double *>(ctx->pin[c & 1]) + a, sizeof(double) * (b - a));
-                done[c].fetch_add(1, std::memory_order_release);
+                const int T = nthreads.load(std::memory_order_acquire);
+                for (size_t c = 0; c < nch; ++c) {
+                    while (ready.load(std::memory_order_acquire) <= (long)c) {
+                        if (failed.load()) return;
+                        std::this_thread::yield();
+                    }
+                    const size_t len = chunk_len(c), per = (len + T - 1) / T, a = std::min(len, per * t), b = std::min(len, a + per);
+                    if (b > a) std::memcpy(dst + c * CHUNK + a, static_cast<const double *>(ctx->pin[c & 1]) + a, sizeof(double) * (b - a));
+                    done[c].fetch_add(1, std::memory_order_release);
+                }
+            });
+    } catch (...) {
+    }
+    const int T = (int)pool.size();
+    if (T == 0 || !done) {  // no helper thread could be started: the plain copy (canonicalised chunk by chunk when asked)
+        failed.store(true);
+        for (auto &th : pool) th.join();
+        for (size_t c = 0; c < nch; ++c) {
+            const size_t len = chunk_len(c);
+            const double *from = src + c * CHUNK;
+            if (canon) {
+                double *stg = static_cast<double *>(ctx->canon[0]->p);
+                HIP_TRY(launch_canon_copy(from, stg, (int64_t)len, ctx->stream));
+                from = stg;
             }
-        });
+            HIP_TRY(hipMemcpyAsync(dst + c * CHUNK, from, sizeof(double) * len, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        return PPCA_OK;
+    }
+    nthreads.store(T, std::memory_order_release);
+    go.store(true, std::memory_order_release);
     hipEvent_t ev[2] = {nullptr, nullptr};
     hipError_t err = hipSuccess;
     auto issue = [&](size_t c) -> hipError_t {
@@ -1304,6 +1336,33 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
     const int64_t sums_at = off[nm], llk_at = sums_at + nm, total = llk_at + 1;
     if (int rc = ensure(ctx->mixpack, ctx->mixpack_cap, sizeof(double) * (size_t)total)) return rc;
     if (int rc = ensure(ctx->mixaux, ctx->mixaux_cap, sizeof(double) * 1024)) return rc;
+    // Every device block the step will ask for is taken HERE, before the first collective: a rank whose allocation fails
+    // returns now, while no peer is inside an all-reduce it would never join (the sizes below are the largest any of the
+    // K llk sweeps and component passes of this call can request).
+    if (n > 0) {
+        size_t max_len = 0, gws_bytes = 0;
+        bool any_fused = false;
+        for (int c = 0; c < nm; ++c) {
+            max_len = std::max(max_len, (size_t)StatsLayout(models_in[c]->d, models_in[c]->k).len);
+            if (ppca_path_kind(models_in[c]->d, models_in[c]->k) == 1) any_fused = true;
+            else gws_bytes = std::max(gws_bytes, generic_workspace_bytes(models_in[c]->d, models_in[c]->k, n));
+        }
+        const int grid = fused_grid(n, ctx->n_cu);
+        if (int rc = ensure(ctx->mix[0], ctx->mix_cap[0], sizeof(double) * (size_t)nm * n)) return rc;
+        if (int rc = ensure(ctx->mix[1], ctx->mix_cap[1], sizeof(double) * (size_t)nm * n)) return rc;
+        if (int rc = ensure(ctx->mix[2], ctx->mix_cap[2], sizeof(double) * (size_t)n)) return rc;
+        if (int rc = ensure(ctx->mix[4], ctx->mix_cap[4], sizeof(double) * (size_t)n)) return rc;
+        if (int rc = ensure(ctx->scal, ctx->scal_cap, sizeof(double) * ((size_t)grid * 8 + 16))) return rc;
+        if (any_fused && n < (int64_t)1 << 31) {
+            if (int rc = ensure(ctx->mix[5], ctx->mix_cap[5], sizeof(int) * (size_t)n)) return rc;
+            if (int rc = ensure(ctx->mix[6], ctx->mix_cap[6], sizeof(int) * ((size_t)select_blocks(n) + 1))) return rc;
+            if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)grid * max_len)) return rc;
+            if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
+            if (int rc = ensure(ctx->errb, ctx->errb_cap, sizeof(double) * (size_t)grid * W_GUARD_NCOL)) return rc;
+        }
+        if (gws_bytes)
+            if (int rc = ensure(ctx->gws, ctx->gws_cap, gws_bytes)) return rc;
+    }
     if (int rc = ensure_hstage(ctx, sizeof(double) * 1024)) return rc;
     double *pack = static_cast<double *>(ctx->mixpack->p);
     double *aux = static_cast<double *>(ctx->mixaux->p);  // [0, 256): maxima -> shifts; [256, 513): new log-weights, llk

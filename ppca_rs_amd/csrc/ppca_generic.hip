@@ -585,31 +585,39 @@ __global__ __launch_bounds__(256) void gen_colscale_kernel(const double *part, i
                                                            int *flags) {
     // one workgroup per column: thread t takes blocks t, t + 256, ..., then a fixed tree over the threads
     // (deterministic; one THREAD per column walked a million-row chunk's 4096 block partials alone: 1 ms per chunk)
-    __shared__ double rmx[256], rsm[256];
+    __shared__ double rmx[256], rsm[256], rmn[256];
     const int c = blockIdx.x, t = threadIdx.x;
-    double mx = 0.0, sm = 0.0;
+    double mx = 0.0, sm = 0.0, mn = __builtin_inf();
     for (int b = t; b < nblocks; b += 256) {
+        const double bs = part[((int64_t)b * 2 + 1) * kp + c];
+        const int64_t rows = (int64_t)(b + 1) * 256 <= n ? 256 : n - (int64_t)b * 256;
         mx = fmax(mx, part[((int64_t)b * 2) * kp + c]);
-        sm += part[((int64_t)b * 2 + 1) * kp + c];
+        sm += bs;
+        mn = fmin(mn, bs / (double)rows);  // the smallest mean magnitude of a 256-row block
     }
     rmx[t] = mx;
     rsm[t] = sm;
+    rmn[t] = mn;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (t < o) {
             rmx[t] = fmax(rmx[t], rmx[t + o]);
             rsm[t] += rsm[t + o];
+            rmn[t] = fmin(rmn[t], rmn[t + o]);
         }
         __syncthreads();
     }
     if (t == 0) {
         mx = rmx[0];
         sm = rsm[0];
+        mn = rmn[0];
         int e = 0;
         if (mx > 0.0 && mx < 1.0e300) (void)frexp(mx, &e);
         scale[c] = ldexp(1.0, e - (7 * GQS - 2));
-        // finite, and the maximum within 2^20 of the mean magnitude
-        if (!(sm < 1.0e300) || !(mx * (double)n <= 1048576.0 * sm)) atomicOr(&flags[1], 1);
+        // finite, and the maximum within 2^20 of the mean magnitude of EVERY 256-row block (round 4: the mean over the whole
+        // chunk is dominated by the very row that breaks the form -- one row at 1e6 x the others passed "max <= 2^20 x mean"
+        // whenever the chunk had fewer than 2^20 rows, and the dimensions masked in that row summed rows cut at 14 bits)
+        if (!(sm < 1.0e300) || !(mx <= 1048576.0 * mn)) atomicOr(&flags[1], 1);
     }
 }
 

@@ -335,3 +335,22 @@ def test_outlier_row_sends_the_statistics_to_fp64(P, oracle, ctx, k, d):
         s1, _, _ = oracle.iterate(xo, s, c, mu)
         new = m.iterate(P.Dataset(xo))
         assert abs(new.isotropic_noise - s1) < 1e-9 * s1 and np.isfinite(new.transform).all()
+
+
+@pytest.mark.parametrize("k,d", [(4, 300), (20, 70)])
+def test_outlier_row_on_the_split_pipeline(P, oracle, ctx, k, d):
+    """The same outlier row on shapes of the generic split pipeline (its int8 statistics product has a per-chunk guard of its
+    own -- column maximum against mean magnitude -- with the fp64 GEMM behind it): every block within 1e-9 of the oracle."""
+    n = 3000
+    rng = np.random.default_rng(5)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 13)
+    x[100] *= 1e6
+    c, mu, s = 0.5 * rng.standard_normal((d, k)), np.zeros(d), 0.7
+    m = P.PPCAModel(s, c, mu)
+    got, want = _stats(P, P.Dataset(x), m), oracle.stats(x, s, c, mu)
+    _assert_stats(got, want, d, k, 1e-9, (k, d))
+    kp = k * (k + 1) // 2
+    diag = [a * (a + 1) // 2 + a for a in range(k)]
+    Sg, Sw = got[d * k:d * k + d * kp].reshape(d, kp), want[d * k:d * k + d * kp].reshape(d, kp)
+    masked = ~np.isfinite(x[100])
+    assert (np.abs(Sg[masked][:, diag] - Sw[masked][:, diag]) / np.abs(Sw[masked][:, diag])).max() < 1e-9
