@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # gfx950 correction calibrated on a known byte count): profiles/r01/README.md
 PMC_BYTES_PER_SAMPLE = 2077.5
 FP64_PEAK_TFLOPS = 78.6  # fp64 vector = fp64 matrix spec (dense MFMA peak for f64)
-TRAFFIC_FILES = ("profiles/r03/traffic.json", "profiles/r02/traffic.json")
+TRAFFIC_FILES = ("profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
 
 
 def algorithmic_bytes_per_sample(d: int) -> float:
@@ -460,10 +460,10 @@ def main() -> None:
                 # config 4: HBM bytes per sample and EM step over EVERY kernel of the split pipeline (2 x FETCH_SIZE + WRITE_SIZE
                 # by separate rocprofv3 PMC passes of tools/pmc_generic.py), committed with the commit it was measured on
                 try:
-                    with open(os.path.join(ROOT, "profiles/r03/traffic_cfg4.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles/r04/traffic_cfg4.json")) as fh:
                         tj = json.load(fh)
                     traffic = tj["hbm_bytes_per_sample"] * rows_local
-                    traffic_src = (f"profiles/r03/traffic_cfg4.json (commit {tj.get('commit')}, {tj.get('n_samples')} rows x {tj.get('em_steps')} EM steps, "
+                    traffic_src = (f"profiles/r04/traffic_cfg4.json (commit {tj.get('commit')}, {tj.get('n_samples')} rows x {tj.get('em_steps')} EM steps, "
                                    "all kernels of one pass; fabric bytes, Infinity-Cache hits included)")
                 except (OSError, KeyError, ValueError):
                     pass
