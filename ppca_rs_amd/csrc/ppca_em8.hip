@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
     if (!front) {
         // =========================================================== back role: P4b on the int8 MFMA
 #ifndef E8_ACC_F64
-#define E8_ACC_F64 0  // 1: the group's exact 24-bit pieces are added to fp64 accumulators (one rounding per piece: three per group
+#define E8_ACC_F64 1  // 1: the group's exact 24-bit pieces are added to fp64 accumulators (one rounding per piece: three per group
                       //    of 64 samples, where a plain fp64 sum takes 64); 0: to int64 accumulators (exact; rounds 3)
 #endif
 #if E8_ACC_F64

@@ -1314,26 +1314,32 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 constexpr double WGUARD_TOL = 5.820766091346741e-11;  // 2^-34
 
 template <int K>
-__global__ __launch_bounds__(256) void wguard_kernel(const double *stats, const double *errb, int grid, int d, int *qflag) {
+__global__ __launch_bounds__(1024) void wguard_kernel(const double *stats, const double *errb, int grid, int d, int *qflag) {
     constexpr int KP = Cfg<K>::KP, NTP = Cfg<K>::NTP;
+    constexpr int NS = 12;  // slices of the workgroups per column: 12 x 80 = 960 threads sum ~grid / 12 bounds each
     __shared__ double es[W_GUARD_NCOL];
-    __shared__ double part3[3][W_GUARD_NCOL];
+    __shared__ double parts[NS][W_GUARD_NCOL];
     const int t = threadIdx.x;
-    if (t < 3 * W_GUARD_NCOL) {  // column t % 80, every third workgroup from t / 80: three independent chains per column
+    if (t < NS * W_GUARD_NCOL) {
         const int c = t % W_GUARD_NCOL, s0 = t / W_GUARD_NCOL;
         double v0 = 0.0, v1 = 0.0;
         if (errb) {
             int b = s0;
-            for (; b + 3 < grid; b += 6) {
+            for (; b + NS < grid; b += 2 * NS) {
                 v0 += errb[(int64_t)b * W_GUARD_NCOL + c];
-                v1 += errb[(int64_t)(b + 3) * W_GUARD_NCOL + c];
+                v1 += errb[(int64_t)(b + NS) * W_GUARD_NCOL + c];
             }
             if (b < grid) v0 += errb[(int64_t)b * W_GUARD_NCOL + c];
         }
-        part3[s0][c] = v0 + v1;
+        parts[s0][c] = v0 + v1;
     }
     __syncthreads();
-    if (t < W_GUARD_NCOL) es[t] = (part3[0][t] + part3[1][t]) + part3[2][t];
+    if (t < W_GUARD_NCOL) {
+        double v = 0.0;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) v += parts[u][t];  // (fixed order)
+        es[t] = v;
+    }
     __syncthreads();
     int unsafe = 0;
     if (errb && t < d) {
@@ -1813,7 +1819,7 @@ hipError_t launch_em_wguard(int k, int grid, PassArgs a, const double *stats, hi
     a.runflag = a.qflag + 8;
     *runflag_out = a.runflag;
     PPCA_DISPATCH_K(k, {
-        hipLaunchKernelGGL((wguard_kernel<KK>), dim3(1), dim3(256), 0, s, stats, errb, grid, a.d, a.qflag);
+        hipLaunchKernelGGL((wguard_kernel<KK>), dim3(1), dim3(1024), 0, s, stats, errb, grid, a.d, a.qflag);
         return (launch_pass_t<KK, true, 4, false>(grid, a, s));
     });
     return hipErrorInvalidValue;

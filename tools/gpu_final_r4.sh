@@ -40,11 +40,11 @@ cd $GRAFT_REPO_ROOT
 # diagnostic builds: per-wave phase table; one-role builds (what each role costs alone); the variants measured this round
 python tools/devbuild.py --timing --name=devt > $OUT/devbuild.log 2>&1
 PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_devt.so python bench.py --n 2000000 --steps 3 --warmup 1 --no-cpu > $OUT/timing.json 2> $OUT/timing.err
-for v in "base" "front -DE8_ONLY_FRONT" "back -DE8_ONLY_BACK" "shared -DE8_SHARED_FACTOR=1" "decoupled -DE8_DECOUPLED=1" "accf64 -DE8_ACC_F64=1" "noearly -DE8_EARLY_DIGDONE=0" "noerrb -DE8_NO_ERRB"; do
+for v in "base" "front -DE8_ONLY_FRONT" "back -DE8_ONLY_BACK" "shared -DE8_SHARED_FACTOR=1" "decoupled -DE8_DECOUPLED=1" "accint64 -DE8_ACC_F64=0" "noearly -DE8_EARLY_DIGDONE=0" "noerrb -DE8_NO_ERRB"; do
   set -- $v; name=$1; shift
   python tools/devbuild.py "$@" --name=v_$name > /dev/null 2>&1
 done
-for rep in 1 2; do for name in base front back shared decoupled accf64 noearly noerrb; do
+for rep in 1 2; do for name in base front back shared decoupled accint64 noearly noerrb; do
   PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_v_$name.so timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
 import json,sys; j=json.loads(sys.stdin.read()); print('$name', round(j['value'],2), 'it/s', round(j['roofline']['kernel_avg_ms'],3), 'ms per launch')"
 done; done > $OUT/variants.log 2>&1
