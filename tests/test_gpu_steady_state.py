@@ -354,3 +354,16 @@ def test_outlier_row_on_the_split_pipeline(P, oracle, ctx, k, d):
     Sg, Sw = got[d * k:d * k + d * kp].reshape(d, kp), want[d * k:d * k + d * kp].reshape(d, kp)
     masked = ~np.isfinite(x[100])
     assert (np.abs(Sg[masked][:, diag] - Sw[masked][:, diag]) / np.abs(Sw[masked][:, diag])).max() < 1e-9
+
+
+def test_heavy_tailed_fuzz_of_the_fixed_point_statistics():
+    """tools/fuzz_gpu2.py: 24 random cases over the three engines (eight-wave kernel, two-kernel pass, split pipeline) with
+    outlier rows (1e2 .. 1e8 x), heavy-tailed weights (log-normal, sigma up to 12), capped grids: the statistics block by block
+    (1e-8) and the diagonal of S and the totals DIMENSION BY DIMENSION (1e-7 element-wise) against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu2.py"), "7", "24"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fuzz2 ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
