@@ -3,9 +3,10 @@
 //
 //   front waves 0-3   P1 staging of a tile's rows, P2 [G | b] (int8-sliced Gram + fp64-MFMA b = X~ C), P3 the
 //                     per-sample k x k solve, P4a the x~-side statistics cross / sumx on the fp64 MFMA
-//   back waves 4-7    P4b: S / U / totals (256 x 66) += Mask^T [wP | wz | w] on the INT8 MFMA with exact 64-bit
-//                     integer accumulation: rows of [wP | wz | w] cut into seven signed bytes of a fixed-point form,
-//                     64 samples (two tiles) per v_mfma_i32_16x16x64_i8, digit sums folded into int64 accumulators
+//   back waves 4-7    P4b: S / U / totals (256 x 66) += Mask^T [wP | wz | w] on the INT8 MFMA: rows of [wP | wz | w] cut
+//                     into seven signed bytes of a fixed-point form, 64 samples (two tiles) per v_mfma_i32_16x16x64_i8,
+//                     the group's exact digit sums recombined into 24-bit pieces and added to fp64 accumulators
+//                     (round 3: int64 accumulators, E8_ACC_F64=0)
 //
 // Why this split (round 3):  v_mfma_f64 shares the SIMD's vector port with every other vector
 // instruction of every wave (tools/ubench_shadow.hip), and P4b was 8.8 k of a tile's 13.9 k fp64-MFMA cycles.  With
@@ -23,10 +24,12 @@
 // maximum + 6.  A later tile whose entry does not fit raises a flag (any exponent field other than 0x433 after the
 // add: too large, infinite or NaN alike); the back waves then contract what is pending under the old exponents,
 // flush the int64 accumulators into the workgroup's partial (x 2^(E_c - 50), fp64), raise the exponents and cut the
-// tile again -- a cold path, taken once at the first tile and whenever a column outgrows its scale.  The integer sums
-// are exact; the only rounding is the cut itself (<= 2^-45 of the column's first-tile maximum per entry) and the one
-// conversion per flush.  A non-finite column poisons its exponent: NaN reaches the statistics as through fp64.
-// Accumulators are also flushed every 100 groups (64 samples x 2^50 per group stay below 2^63).
+// tile again -- a cold path, taken once at the first tile and whenever a column outgrows its scale.  The digit sums of a
+// group are exact; the roundings are the cut itself (<= 2^-45 of the column's first-tile maximum per entry), one fp64
+// addition per 24-bit piece and one multiplication per flush.  A non-finite column poisons its exponent: NaN reaches the
+// statistics as through fp64.  Accumulators are also flushed every 100 groups (int64 form: 64 samples x 2^50 per group
+// stay below 2^63).  Whether the cut was fine enough for the data at hand is checked on the REDUCED statistics by
+// wguard_kernel (ppca_kernels.hip) from the per-column rounding bounds this role reports (p.errb).
 //
 // Hand-off (all in LDS): the front writes the tile's [wP | wz | w] rows in P3, ONE workgroup barrier per tile; the back
 // cuts them into digit planes (even tile of a group: its own region; odd tile: the [G | b] buffer, free after P3) and
