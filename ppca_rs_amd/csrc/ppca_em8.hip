@@ -767,6 +767,35 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                 load_pair(qbB, 0);
             }
             {
+#ifdef E8_C_GLOBAL
+                // EXPERIMENT: the B operands from the zero-padded copy of C in global memory (L1 / L2) instead of the LDS tile
+                // (would free 22.5 KB of LDS), requested two chunks of four k-steps ahead
+                constexpr int CH = 4, NCH = STEPS / CH;
+                const double *cg = p.cpad + (DPS * kq + l4) * CS + colb;
+                double axb[2][CH], cbb[3][CH];
+#pragma unroll
+                for (int c0 = 0; c0 < 2; ++c0)
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) cbb[c0][u] = cg[4 * (c0 * CH + u) * CS];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) axb[0][u] = xrow[4 * u];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + 1 < NCH) {
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
+                    }
+                    if (c + 2 < NCH) {
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) cbb[(c + 2) % 3][u] = cg[4 * ((c + 2) * CH + u) * CS];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) accb = mfma(axb[c & 1][u], cbb[c % 3][u], accb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
                 // b = X~ C: operands of the next four k-steps are requested before the current four MFMAs issue
                 constexpr int CH = 4;
                 double axb[2][CH], cbb[2][CH];
@@ -790,6 +819,7 @@ __global__ __launch_bounds__(512) void em8_kernel(PassArgs p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#endif
             group(qbA, false);  // digits {3,2}
             group(qbB, false);  // digits {1,0}
             E8_STAMP(0)

@@ -49,6 +49,7 @@ struct PassArgs {
     // EM mode, the guard of the int8 form of the mask-side statistics (launch_em_wguard):
     double *errb;         // [grid][W_GUARD_NCOL]: per workgroup and column of [wP | wz | w], a bound of the rounding the fixed-point
                           // cut added to any sum of that column (written by em8_kernel; nullptr: not collected)
+    const double *cpad;   // experiment (-DE8_C_GLOBAL): zero-padded copy of C, [256][k + 1], written by qprep_kernel
     const int *runflag;   // nullable: the fp64 instantiation of pass_kernel runs iff *runflag != 0 (set by wguard_kernel from the
                           // Gram flags and the W-side check); nullptr: qflag decides as before
 };

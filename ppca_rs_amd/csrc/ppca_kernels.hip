@@ -133,6 +133,15 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     __syncthreads();
     if (j == 0) qflag[t] = bad;
     if (j == 0 && t == 0) qflag[8] = qflag[9] = 0;  // the pass's run-again flag and the W-side verdict (wguard_kernel)
+#ifdef E8_C_GLOBAL
+    if (t == 0) {  // zero-padded copy of C for the experiment that reads the B operands of b = X~ C from L2 instead of LDS
+        double *cp = reinterpret_cast<double *>(qtab + qtab_bytes<FUSED_MAX_K>());
+        for (int idx = j; idx < FUSED_MAX_D * (K + 1); idx += 256) {
+            const int jj = idx / (K + 1), a2 = idx - jj * (K + 1);
+            cp[idx] = (jj < d && a2 < K) ? model[MODEL_HDR + (int64_t)jj * K + a2] : 0.0;
+        }
+    }
+#endif
     const int lane = j & 63, kc = j >> 6;
     const int c = 16 * t + (lane & 15);
     int a = 0;
@@ -1701,11 +1710,12 @@ static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-size_t fused_qtab_bytes() { return qtab_bytes<FUSED_MAX_K>() + 72 * sizeof(double); }
+size_t fused_qtab_bytes() { return qtab_bytes<FUSED_MAX_K>() + (72 + FUSED_MAX_D * (FUSED_MAX_K + 1)) * sizeof(double); }
 void fused_qtab_layout(void *base, PassArgs &a) {  // [64 scales | 8 doubles of guard flags | digit table]
     a.qscale = static_cast<double *>(base);
     a.qflag = reinterpret_cast<int *>(a.qscale + 64);
     a.qtab = reinterpret_cast<signed char *>(a.qscale + 72);
+    a.cpad = reinterpret_cast<const double *>(a.qtab + qtab_bytes<FUSED_MAX_K>());  // (behind the largest table)
 }
 
 // Gram engine of the fused passes: 0 = int8-sliced MFMA behind the dynamic-range guard, with the fp64-MFMA instantiation
