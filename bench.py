@@ -439,7 +439,7 @@ def main() -> None:
             flops_reference = nm * rows_local * (algorithmic_flops_llk_per_sample(k, m_obs) + algorithmic_flops_per_sample(d, k, m_obs))
             tflops, gbs = flops_step / t_step / 1e12, bytes_step / t_step / 1e9
             fp64_bound = False  # the mixture is reported against the ONE-pass byte figure (X read once per iteration)
-            kernel_name = (f"one mixture EM iteration = {nm} llk2_kernel<{k}> sweeps + {nm} gathered em8_kernel<{k}, true> passes + "
+            kernel_name = (f"one mixture EM iteration = {nm} llk2_kernel<{k}> sweeps + {nm} gathered em9_kernel<{k}, true> passes + "
                            "finalisations (timed as one region: ONE C-ABI call)")
             kern_avg_ms, launches_rep = 1e3 * t_step, args.steps
             traffic, traffic_src = None, None
@@ -472,8 +472,10 @@ def main() -> None:
                     kernel_name = f"ppca::pass_kernel<{k}, true, 4, false, false>"  # the guard's fallback engine
                 elif os.environ.get("PPCA_EM8") == "0":
                     kernel_name = f"ppca::pass_kernel<{k}, true, 4, true, false>"
-                else:
+                elif os.environ.get("PPCA_EM9") == "0":
                     kernel_name = f"ppca::em8_kernel<{k}, false>"
+                else:
+                    kernel_name = f"ppca::em9_kernel<{k}, false>"
             elif d <= 256 and 11 <= k <= 16 and os.environ.get("PPCA_EM16") != "0":
                 kernel_name = (f"ppca::estep16_kernel<{k}> + ppca::sstat16_kernel<{k}> per chunk of 2^20 rows (the two fused kernels of "
                                "one pass and their partial reduction, timed as one region)")

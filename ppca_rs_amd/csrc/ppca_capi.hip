@@ -1568,6 +1568,14 @@ extern "C" int ppca_debug_counters(ppca_ctx *ctx, int64_t *out8, int32_t reset) 
     USE_CTX(ctx);
     unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(em8_debug_counters(c, reset, ctx->stream));
+    {  // (PPCA_EM9=1: the pipelined-solve variant keeps its own; reported in the same slots)
+        unsigned long long c9[4] = {0, 0, 0, 0};
+        HIP_TRY(em9_debug_counters(c9, reset, ctx->stream));
+        c[0] += c9[0];
+        c[1] += c9[1];
+        c[2] = std::max(c[2], c9[2]);
+        c[3] += c9[3];
+    }
     HIP_TRY(em16_debug_counters(c + 4, reset, ctx->stream));
     for (int i = 0; i < 8; ++i) out8[i] = (int64_t)c[i];
     return PPCA_OK;

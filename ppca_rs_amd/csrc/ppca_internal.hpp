@@ -49,7 +49,7 @@ struct PassArgs {
     // EM mode, the guard of the int8 form of the mask-side statistics (launch_em_wguard):
     double *errb;         // [grid][W_GUARD_NCOL]: per workgroup and column of [wP | wz | w], a bound of the rounding the fixed-point
                           // cut added to any sum of that column (written by em8_kernel; nullptr: not collected)
-    const double *cpad;   // experiment (-DE8_C_GLOBAL): zero-padded copy of C, [256][k + 1], written by qprep_kernel
+    const double *cpad;   // zero-padded copy of C, [256][k + 1], written by qprep_kernel (ppca_em9.hip; em8's -DE8_C_GLOBAL)
     const int *runflag;   // nullable: the fp64 instantiation of pass_kernel runs iff *runflag != 0 (set by wguard_kernel from the
                           // Gram flags and the W-side check); nullptr: qflag decides as before
 };
@@ -71,6 +71,10 @@ hipError_t launch_pass_post(int k, int grid, const PassArgs &a, hipStream_t s);
 // waves contract the mask-side statistics on the int8 MFMA.  Honours a.qflag like the int8 instantiation of pass_kernel.
 bool em8_covers(int k);
 hipError_t launch_em8(int k, int grid, const PassArgs &a, hipStream_t s);
+// The same with the per-sample solve pipelined across tiles (ppca_em9.hip; PPCA_EM9=1).
+bool em9_covers(int k);
+hipError_t launch_em9(int k, int grid, const PassArgs &a, hipStream_t s);
+hipError_t em9_debug_counters(unsigned long long *out4, int reset, hipStream_t s);
 // The EM pass for 11 <= k <= 16, d <= 256 as two fused kernels (ppca_em16.hip): E-step sweep over X writing the rows
 // [wP | wz | w] and the tiles' sample masks, then the mask-side statistics on the int8 MFMA.  Both write disjoint parts of
 // part[grid][stats_len] (reduce with launch_reduce_partials).

@@ -133,15 +133,17 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     __syncthreads();
     if (j == 0) qflag[t] = bad;
     if (j == 0 && t == 0) qflag[8] = qflag[9] = 0;  // the pass's run-again flag and the W-side verdict (wguard_kernel)
-#ifdef E8_C_GLOBAL
-    if (t == 0) {  // zero-padded copy of C for the experiment that reads the B operands of b = X~ C from L2 instead of LDS
+    // zero-padded copy of C: ppca_em9.hip (and em8's -DE8_C_GLOBAL experiment) read the B operands of b = X~ C from it.  Only
+    // in the layout of fused_qtab_layout (k <= FUSED_MAX_K: the copy sits behind the largest table); the callers with their
+    // own, exactly sized tables (ppca_em16.hip's, k = 11..16) have no room behind them -- round 4 found that the hard way:
+    // the copy went over the two-kernel pass's workspace.
+    if (t == 0 && K <= FUSED_MAX_K) {
         double *cp = reinterpret_cast<double *>(qtab + qtab_bytes<FUSED_MAX_K>());
         for (int idx = j; idx < FUSED_MAX_D * (K + 1); idx += 256) {
             const int jj = idx / (K + 1), a2 = idx - jj * (K + 1);
             cp[idx] = (jj < d && a2 < K) ? model[MODEL_HDR + (int64_t)jj * K + a2] : 0.0;
         }
     }
-#endif
     const int lane = j & 63, kc = j >> 6;
     const int c = 16 * t + (lane & 15);
     int a = 0;
@@ -1744,6 +1746,16 @@ static bool em8_enabled() {
     return v;
 }
 
+// The eight-wave kernel with the per-sample solve pipelined across tiles (ppca_em9.hip; default since the end of round 4:
+// 98.0 against 96.1 EM it/s, every GPU test green on both).  PPCA_EM9=0: ppca_em8.hip's kernel.
+static bool em9_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_EM9");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+
 static bool llk2_enabled() {
     static const bool v = [] {
         const char *e = getenv("PPCA_LLK2");
@@ -1771,6 +1783,7 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
             if (!b.states && !b.covs && !b.recon && llk2_enabled()) return launch_llk2(K, grid, b, s);
         }
         if constexpr (EM) {
+            if (em9_enabled() && em9_covers(K)) return launch_em9(K, grid, b, s);  // ... with the solve pipelined across tiles
             if (em8_enabled() && em8_covers(K)) return launch_em8(K, grid, b, s);  // eight waves, two roles (ppca_em8.hip)
             if (b.rows) return launch_pass_t<K, EM, 4, true, true>(grid, b, s);
         }
@@ -1825,7 +1838,7 @@ hipError_t launch_em_wguard(int k, int grid, PassArgs a, const double *stats, hi
     return hipSuccess;  // kernel-tuning builds instantiate the int8 variants only
 #else
     if (gram_mode() != 0) return hipSuccess;  // engine pinned: nothing to decide
-    const double *errb = (em8_enabled() && em8_covers(k)) ? a.errb : nullptr;  // (only em8_kernel cuts its rows)
+    const double *errb = (em8_enabled() && em8_covers(k)) ? a.errb : nullptr;  // (only em8_kernel / em9_kernel cut their rows)
     a.runflag = a.qflag + 8;
     *runflag_out = a.runflag;
     PPCA_DISPATCH_K(k, {

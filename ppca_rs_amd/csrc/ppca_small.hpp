@@ -258,6 +258,33 @@ PPCA_HD constexpr int pair_owner(int K, int p, int nw) {
     return own;
 }
 
+// The same balance over nw EQUAL workers (ppca_em9.hip: the three front waves that are not the tile's solver).
+PPCA_HD constexpr int pair_owner_eq(int K, int p, int nw, int handicap_last = 0) {
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    load[nw - 1] = handicap_last;  // what the last worker does besides (the per-sample scalars: ~107 of these units)
+    int own = 0;
+    for (int pp = 0; pp <= p; ++pp) {
+        own = 0;
+        for (int w = 1; w < nw; ++w)
+            if (load[w] < load[own]) own = w;
+        const int c0 = 2 * pp;
+        load[own] += (K - c0) * (K - c0) + 4 * (K - c0);
+    }
+    return own;
+}
+PPCA_HD constexpr int column_owner_eq(int K, int c, int nw, int handicap_last = 0) {
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    load[nw - 1] = handicap_last;
+    int own = 0;
+    for (int cc = 0; cc <= c; ++cc) {
+        own = 0;
+        for (int w = 1; w < nw; ++w)
+            if (load[w] < load[own]) own = w;
+        load[own] += (K - cc) * (K - cc) + 4 * (K - cc);
+    }
+    return own;
+}
+
 // true when no earlier pair belongs to pair p's owner (that pair's part of the factor covers the owner's later pairs)
 PPCA_HD constexpr bool pair_first_of_owner(int K, int p, int nw) {
     for (int q = 0; q < p; ++q)

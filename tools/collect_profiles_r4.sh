@@ -5,7 +5,7 @@ set -e
 R=/root/repo; S=$R/gpurun_out/r4f; D=$R/profiles/r04
 mkdir -p $D $D/cliff
 first() { ls -t $(find "$1" -name "$2") | head -1; }
-for f in bench_n10m bench_n10m_fp64gram bench_n10m_em4 bench_cfg5 bench_cfg5_llk2 bench_cfg4; do cp $S/$f.json $D/$f.json; done
+for f in bench_n10m bench_n10m_fp64gram bench_n10m_em4 bench_n10m_em8 bench_cfg5 bench_cfg5_llk2 bench_cfg4; do cp $S/$f.json $D/$f.json; done
 cp $S/traffic.json $D/traffic.json
 cp $S/kt_bench.json $D/bench_n10m_under_rocprof.json
 cp $(first $S/kt "*kernel_stats.csv") $D/bench_n10m_kernel_stats.csv
@@ -17,8 +17,9 @@ cp $(first $S/pmc_write "*counter_collection.csv") $D/pmc_n10m_WRITE_SIZE_counte
 cp $(first $S/pmc_mfma "*counter_collection.csv") $D/pmc_n1m_mfma_counter_collection.csv
 cp $(first $S/pmc_inst "*counter_collection.csv") $D/pmc_n1m_inst_counter_collection.csv
 cp $S/weighted_n10m.log $S/passes.log $S/passes_llk2.log $S/passes_d200_k16.log $S/additivity_n10m.log $S/outlier_probe.log $D/
-grep -E "^(base|front|back|shared|decoupled|accf64|noearly|noerrb|accint64) " $S/variants.log > $D/variants.log
+grep -E "^(em9|em9front|em9back|base|front|back|shared|decoupled|accf64|noearly|noerrb|accint64) " $S/variants.log > $D/variants.log
 grep "em8 wave\|em8 cycles" $S/timing.err | tail -9 > $D/em8_phase_table.log
+grep "em8 wave" $S/timing_em9.err | tail -8 | sed "s/em8 wave/em9 wave/" > $D/em9_phase_table.log
 cp $S/cliff_d*.json $D/cliff/
 python3 - <<PY
 import json, glob

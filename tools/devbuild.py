@@ -9,6 +9,7 @@ flags = ["-DPPCA_DEV_K10"] + [a for a in sys.argv[1:] if a.startswith("-D")] + (
 base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags]
 procs = [subprocess.Popen(base + ["-c", os.path.join(C, "ppca_kernels.hip"), "-o", "/tmp/ppca_kernels.dev.o"]),
          subprocess.Popen(base + ["-c", os.path.join(C, "ppca_em8.hip"), "-o", "/tmp/ppca_em8.dev.o"]),
+         subprocess.Popen(base + ["-c", os.path.join(C, "ppca_em9.hip"), "-o", "/tmp/ppca_em9.dev.o"]),
          subprocess.Popen(base + ["-c", os.path.join(C, "ppca_llk.hip"), "-o", "/tmp/ppca_llk.dev.o"])]
 if "--timing" in sys.argv:  # ppca_capi prints the phase table only when built with the flag
     procs.append(subprocess.Popen(base + ["-c", os.path.join(C, "ppca_capi.hip"), "-o", "/tmp/ppca_capi.dev.o"]))
@@ -19,6 +20,6 @@ assert all(p.wait() == 0 for p in procs)
 capi = "/tmp/ppca_capi.dev.o" if "--timing" in sys.argv else os.path.join(C, "ppca_capi.o")
 name = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--name=")]
 out = os.path.join(ROOT, "ppca_rs_amd", "libppca_hip_%s.so" % (name[0] if name else "dev"))
-subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out, "/tmp/ppca_kernels.dev.o", "/tmp/ppca_em8.dev.o", "/tmp/ppca_llk.dev.o",
+subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out, "/tmp/ppca_kernels.dev.o", "/tmp/ppca_em8.dev.o", "/tmp/ppca_em9.dev.o", "/tmp/ppca_llk.dev.o",
                                   os.path.join(C, "ppca_generic.o"), os.path.join(C, "ppca_em16.o"), os.path.join(C, "ppca_comm.o"), capi])
 print(out)

@@ -18,6 +18,7 @@ cd $GRAFT_REPO_ROOT
 python bench.py > $OUT/bench_n10m.json 2> $OUT/bench_n10m.err
 python bench.py --gram fp64 --steps 10 --warmup 2 --no-cpu > $OUT/bench_n10m_fp64gram.json 2> $OUT/bench_n10m_fp64gram.err
 PPCA_EM8=0 python bench.py --steps 10 --warmup 2 --no-cpu > $OUT/bench_n10m_em4.json 2> $OUT/bench_n10m_em4.err
+PPCA_EM9=0 python bench.py --steps 10 --warmup 2 --no-cpu > $OUT/bench_n10m_em8.json 2> $OUT/bench_n10m_em8.err
 python tools/time_weighted.py 10000000 256 10 2>&1 | grep -v amdgpu.ids > $OUT/weighted_n10m.log
 python bench.py --config 5 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
 PPCA_LLK8=0 python bench.py --config 5 --no-cpu > $OUT/bench_cfg5_llk2.json 2> $OUT/bench_cfg5_llk2.err
@@ -39,13 +40,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_d200_k16 -- pyth
 cd $GRAFT_REPO_ROOT
 # diagnostic builds: per-wave phase table; one-role builds (what each role costs alone); the variants measured this round
 python tools/devbuild.py --timing --name=devt > $OUT/devbuild.log 2>&1
-PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_devt.so python bench.py --n 2000000 --steps 3 --warmup 1 --no-cpu > $OUT/timing.json 2> $OUT/timing.err
-for v in "base" "front -DE8_ONLY_FRONT" "back -DE8_ONLY_BACK" "shared -DE8_SHARED_FACTOR=1" "decoupled -DE8_DECOUPLED=1" "accint64 -DE8_ACC_F64=0" "noearly -DE8_EARLY_DIGDONE=0" "noerrb -DE8_NO_ERRB"; do
+PPCA_EM9=0 PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_devt.so python bench.py --n 2000000 --steps 3 --warmup 1 --no-cpu > $OUT/timing.json 2> $OUT/timing.err
+PPCA_EM9=1 PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_devt.so python bench.py --n 2000000 --steps 3 --warmup 1 --no-cpu > $OUT/timing_em9.json 2> $OUT/timing_em9.err
+for v in "em9 -DNOTHING" "em9front -DE9_ONLY_FRONT" "em9back -DE9_ONLY_BACK" "base" "front -DE8_ONLY_FRONT" "back -DE8_ONLY_BACK" "shared -DE8_SHARED_FACTOR=1" "decoupled -DE8_DECOUPLED=1" "accint64 -DE8_ACC_F64=0" "noearly -DE8_EARLY_DIGDONE=0" "noerrb -DE8_NO_ERRB"; do
   set -- $v; name=$1; shift
   python tools/devbuild.py "$@" --name=v_$name > /dev/null 2>&1
 done
-for rep in 1 2; do for name in base front back shared decoupled accint64 noearly noerrb; do
-  PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_v_$name.so timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
+for rep in 1 2; do for name in em9 em9front em9back base front back shared decoupled accint64 noearly noerrb; do
+  E9=0; case $name in em9*) E9=1;; esac
+  PPCA_EM9=$E9 PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_v_$name.so timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
 import json,sys; j=json.loads(sys.stdin.read()); print('$name', round(j['value'],2), 'it/s', round(j['roofline']['kernel_avg_ms'],3), 'ms per launch')"
 done; done > $OUT/variants.log 2>&1
 ls -la $OUT

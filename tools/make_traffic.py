@@ -19,8 +19,10 @@ def mean(path, counter, needle):
 def main():
     fdir, wdir, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     commit = sys.argv[5] if len(sys.argv) > 5 else None
-    K = "em8_kernel<10, false, false>"
     fcsv, wcsv = first_csv(fdir), first_csv(wdir)
+    K = "em9_kernel<10, false, false>"  # the default EM kernel since the end of round 4 (PPCA_EM9=0: em8_kernel)
+    if mean(fcsv, "FETCH_SIZE", K)[1] == 0:
+        K = "em8_kernel<10, false, false>"
     f, nf = mean(fcsv, "FETCH_SIZE", K)
     w, _ = mean(wcsv, "WRITE_SIZE", K)
     cal, _ = mean(fcsv, "FETCH_SIZE", "column_presence_kernel")
