@@ -1783,7 +1783,7 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
             if (!b.states && !b.covs && !b.recon && llk2_enabled()) return launch_llk2(K, grid, b, s);
         }
         if constexpr (EM) {
-            if (em9_enabled() && em9_covers(K)) return launch_em9(K, grid, b, s);  // ... with the solve pipelined across tiles
+            if (em8_enabled() && em9_enabled() && em9_covers(K)) return launch_em9(K, grid, b, s);  // ... with the solve pipelined across tiles (PPCA_EM8=0 switches both eight-wave kernels off)
             if (em8_enabled() && em8_covers(K)) return launch_em8(K, grid, b, s);  // eight waves, two roles (ppca_em8.hip)
             if (b.rows) return launch_pass_t<K, EM, 4, true, true>(grid, b, s);
         }
