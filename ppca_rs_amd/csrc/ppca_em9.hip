@@ -46,7 +46,7 @@ constexpr int E9_FLUSH_GROUPS = 100;
 #endif
 
 #ifdef PPCA_PHASE_TIMING  // per-wave phase sums into PassArgs::dbg (printed by ppca_capi.hip with em8's column names)
-#define E9_FINE(i) { long long tn = clock64(); tfine[i] += tn - tfl; tfl = tn; }
+#define E9_FINE(i) { __builtin_amdgcn_sched_barrier(0); long long tn = clock64(); tfine[i] += tn - tfl; tfl = tn; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define E9_FINE(i)
 #endif
