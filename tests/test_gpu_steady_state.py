@@ -367,3 +367,18 @@ def test_heavy_tailed_fuzz_of_the_fixed_point_statistics():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu2.py"), "7", "24"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fuzz2 ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("em9", ["0", "1"])
+def test_both_eight_wave_kernels_against_the_oracle(em9):
+    """tools/em9_check.py in a child process (the switch is read once per process): em9_kernel (the default: the solve
+    pipelined across tiles) and em8_kernel (PPCA_EM9=0, round 3's) at N = 20 000 on the full grid and on 2 / 1 workgroups,
+    weighted and not, and on ragged shapes down to one row -- every block of the statistics within 1e-9 of the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PPCA_EM9=em9)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "em9_check.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "em9 check ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
