@@ -780,13 +780,23 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                     double pm = 1.0;
                     int pe = 0;
                     double z[K], quad = 0.0, zz = 0.0;
+#ifdef E9_EXP_NOLOAD  // (timing experiments, results wrong: what each part of the solver's trip costs)
+                    fac.load([&](int e) { return (double)(e + 1) * s2; }, s2);
+#pragma unroll
+                    for (int a = 0; a < K; ++a) z[a] = s2 + (double)a;
+#else
                     fac.load([&](int e) { return g0[e]; }, s2);
 #pragma unroll
                     for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a] + b1[a];
+#endif
                     E9_FINE(7)   // "solve" column of the table: the solver's loads
+#ifndef E9_EXP_NOFACTOR
                     fac.factor_loaded(pm, pe);
+#endif
                     E9_FINE(9)   // "scalars": its factorisation
+#ifndef E9_EXP_NOSOLVE
                     fac.solve_loaded(z, quad, zz);
+#endif
                     E9_FINE(10)  // "wg-barrier": its substitutions; "factor": its write-back
                     if (hi == 0) {
                         // the factor ENTRY-major over the G part of the tile's buffer (entry e of sample i at row e / 2, column
