@@ -15,8 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppca_hip.so")
-SOURCES = ["ppca_kernels.hip", "ppca_em8.hip", "ppca_em9.hip", "ppca_em16.hip", "ppca_llk.hip", "ppca_generic.hip", "ppca_capi.hip", "ppca_comm.hip"]
-DEPS = SOURCES + ["ppca_small.hpp", "ppca_internal.hpp", "ppca_handles.hpp", "ppca_device.hpp", os.path.join("..", "..", "include", "ppca_hip.h")]
+SOURCES = ["ppca_kernels.hip", "ppca_em8.hip", "ppca_em9.hip", "ppca_em16.hip", "ppca_llk.hip", "ppca_generic.hip", "ppca_solve4.hip", "ppca_capi.hip", "ppca_comm.hip"]
+DEPS = SOURCES + ["ppca_small.hpp", "ppca_internal.hpp", "ppca_solve.hpp", "ppca_handles.hpp", "ppca_device.hpp", os.path.join("..", "..", "include", "ppca_hip.h")]
 
 
 def _hipcc() -> str:

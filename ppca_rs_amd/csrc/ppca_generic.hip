@@ -20,6 +20,7 @@
 #include <utility>
 
 #include "ppca_internal.hpp"
+#include "ppca_solve.hpp"
 
 namespace ppca {
 
@@ -959,23 +960,7 @@ __device__ void wave_chol_inverse(const double *Mw, double *Uw, int k, int LD, i
 }
 
 // ------------------------------------------------------------------ per-sample solve
-struct SolveArgs {
-    double *G;        // [n][kp] in: packed Gram; out (EM): w P packed
-    double *Bz;       // [n][k+1] in: b (k); out (EM): [w z | w]
-    const double *xx; // [n]
-    const double *mc; // [n]
-    const double *w;  // [n] or nullptr
-    int64_t n;
-    int k;
-    const double *model;  // device model buffer: sigma^2 and ln sigma are read on the device
-    double *sc;       // [n][4]: sq, dev, w*llk, nonempty  (EM: sq/dev filled; post: only llk)
-    int em;
-    double *llks;     // post (nullable): per-sample llk
-    double *states;   // post (nullable): [n][k]
-    double *covs;     // post (nullable): [n][k][k]
-    int need_sigma;   // post: some consumer reads the packed Sigma the solver leaves in G (covariances, their diagonals);
-                      // 0: the lane-per-sample solver skips the k inverse columns (llk, states, smooth, extrapolate)
-};
+// (SolveArgs: ppca_solve.hpp)
 
 __global__ __launch_bounds__(128) void solve_kernel(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) double gsm[];
@@ -1786,6 +1771,11 @@ static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
 #undef PPCA_LANE_CASE
         }
     }
+    static const bool batched = [] {  // PPCA_SOLVE4=0: one sample per wave (solve_mfma_body; the form of rounds 2-4, A/B runs)
+        const char *e = getenv("PPCA_SOLVE4");
+        return !(e && atoi(e) == 0);
+    }();
+    if (!reg && form == 0 && batched && solve4_covers(a.k)) return launch_solve4(a, n_cu, s);
     if (!reg && form == 0) {
         if (a.k <= 16) return launch_solve_mfma<1>(a, n_cu, s);
         if (a.k <= 32) return launch_solve_mfma<2>(a, n_cu, s);

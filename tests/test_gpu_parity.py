@@ -596,7 +596,9 @@ def test_full_size_properties(P):
 
 @pytest.mark.parametrize("n,d,k,mp,block", [(600, 300, 4, 0.3, False), (800, 200, 16, 0.2, False),
                                             (257, 1024, 64, 0.5, True), (90, 40, 12, 0.4, False),
-                                            (300, 70, 20, 0.3, False), (200, 513, 10, 0.3, False)])
+                                            (300, 70, 20, 0.3, False), (200, 513, 10, 0.3, False),
+                                            (301, 80, 40, 0.3, False), (203, 64, 32, 0.3, False), (7, 40, 17, 0.2, False),
+                                            (130, 70, 48, 0.2, False), (66, 90, 49, 0.1, False)])
 def test_generic_pipeline_matches_oracle(P, oracle, n, d, k, mp, block):
     """Shapes outside the fused kernel (d > 256 or k > 10) run the split pipeline
     (ppca_generic.hip); BASELINE config 4 (d = 1024, k = 64, 50 % block-masked) at oracle-sized N."""

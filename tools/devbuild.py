@@ -21,5 +21,5 @@ capi = "/tmp/ppca_capi.dev.o" if "--timing" in sys.argv else os.path.join(C, "pp
 name = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--name=")]
 out = os.path.join(ROOT, "ppca_rs_amd", "libppca_hip_%s.so" % (name[0] if name else "dev"))
 subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out, "/tmp/ppca_kernels.dev.o", "/tmp/ppca_em8.dev.o", "/tmp/ppca_em9.dev.o", "/tmp/ppca_llk.dev.o",
-                                  os.path.join(C, "ppca_generic.o"), os.path.join(C, "ppca_em16.o"), os.path.join(C, "ppca_comm.o"), capi])
+                                  os.path.join(C, "ppca_generic.o"), os.path.join(C, "ppca_solve4.o"), os.path.join(C, "ppca_em16.o"), os.path.join(C, "ppca_comm.o"), capi])
 print(out)
