@@ -231,6 +231,17 @@ def traffic_from_profiles(rows_local: int):
     return PMC_BYTES_PER_SAMPLE * rows_local, "profiles/r01/README.md (N = 2 M, round-1 build)"
 
 
+def sustained_mfma_from_profiles():
+    """What a loop of nothing but independent MFMAs sustains on this part (tools/mfma_peak, run on the GPU box before the
+    bench line; reported beside the guide's nominal peak, never instead of it)."""
+    try:
+        with open(os.path.join(ROOT, "profiles/r04/mfma_peak.json")) as fh:
+            pj = json.load(fh)
+        return pj
+    except (OSError, ValueError):
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -504,6 +515,13 @@ def main() -> None:
             "note": "bound = the larger of (algorithmic bytes / HBM peak) and (algorithmic fp64 flops / dense fp64 MFMA peak) "
                     "per sample (SURVEY.md 8d): 0.261 ns vs 0.687 ns at d=256, k=10, so the fp64 pipe; hbm_* = the other one",
         }
+        sus = sustained_mfma_from_profiles()
+        if sus and fp64_bound:
+            roofline["sustained_mfma"] = {
+                "fp64_tflops": sus["fp64_16x16x4_tflops_best"], "int8_pops": sus["int8_16x16x64_pops_best"],
+                "frac_of_sustained_fp64": tflops / sus["fp64_16x16x4_tflops_best"],
+                "source": "profiles/r04/mfma_peak.json (tools/mfma_peak: back-to-back independent MFMAs, no memory traffic; commit %s)" % sus.get("commit"),
+            }
         if mixture:
             roofline["note"] = ("frac = SURVEY.md 8(d)'s ONE-pass bytes (N x 2088 B: X read once per iteration) / step time / HBM peak; "
                                 "fp64_* = the flops the step EXECUTED (K llk sweeps over all rows + the EM flops of the rows each "

@@ -7,6 +7,7 @@ mkdir -p $D $D/cliff
 first() { ls -t $(find "$1" -name "$2") | head -1; }
 for f in bench_n10m bench_n10m_fp64gram bench_n10m_em4 bench_n10m_em8 bench_cfg5 bench_cfg5_llk2 bench_cfg4; do cp $S/$f.json $D/$f.json; done
 cp $S/traffic.json $D/traffic.json
+cp $S/mfma_peak.json $D/mfma_peak.json; cp $S/mfma_peak.txt $D/mfma_peak.txt; cp $S/solve4_ab.log $S/s4bench.log $D/
 cp $S/kt_bench.json $D/bench_n10m_under_rocprof.json
 cp $(first $S/kt "*kernel_stats.csv") $D/bench_n10m_kernel_stats.csv
 cp $(first $S/kt_cfg5 "*kernel_stats.csv") $D/bench_cfg5_kernel_stats.csv

@@ -6,6 +6,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/r4f
 mkdir -p $OUT $GRAFT_REPO_ROOT/profiles/r04
 cd /tmp && export TMPDIR=/tmp
 COMMIT=$(cat $GRAFT_REPO_ROOT/tools/commit_stamp.txt 2>/dev/null)
+# what the part sustains on nothing but MFMAs (cited beside the nominal peak by bench.py)
+$GRAFT_REPO_ROOT/tools/mfma_peak/mfma_peak "$COMMIT" > $OUT/mfma_peak.txt 2>&1
+tail -1 $OUT/mfma_peak.txt > $GRAFT_REPO_ROOT/profiles/r04/mfma_peak.json
+cp $GRAFT_REPO_ROOT/profiles/r04/mfma_peak.json $OUT/mfma_peak.json
 export PMC_N=10000000
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/tools/pmc_run.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/pmc_run.py > $OUT/pmc_write.log 2>&1
@@ -23,10 +27,21 @@ python tools/time_weighted.py 10000000 256 10 2>&1 | grep -v amdgpu.ids > $OUT/w
 python bench.py --config 5 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
 PPCA_LLK8=0 python bench.py --config 5 --no-cpu > $OUT/bench_cfg5_llk2.json 2> $OUT/bench_cfg5_llk2.err
 python bench.py --config 4 --steps 5 --warmup 1 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
-for s in "200 16" "256 11" "256 13" "256 16" "300 10" "512 10" "256 10" "200 10" "256 20"; do
+for s in "200 16" "256 11" "256 13" "256 16" "300 10" "512 10" "256 10" "200 10" "256 20" "256 32" "256 48"; do
   set -- $s
   python bench.py --n 2000000 --d $1 --k $2 --steps 4 --warmup 1 --no-cpu > $OUT/cliff_d$1_k$2.json 2> $OUT/cliff_d$1_k$2.err
 done
+# the batched blocked solver (ppca_solve4.hip) against the one-sample-per-wave form it replaces, same run
+for rep in 1 2; do for v in 1 0; do
+  for s in "256 20" "256 32" "256 48"; do
+    set -- $s
+    PPCA_SOLVE4=$v python bench.py --n 2000000 --d $1 --k $2 --steps 4 --warmup 1 --no-cpu 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read()); print('PPCA_SOLVE4=$v d=$1 k=$2', round(j['ms_per_step'],2), 'ms per EM iteration')"
+  done
+  PPCA_SOLVE4=$v python bench.py --config 4 --steps 3 --warmup 1 --no-cpu 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read()); print('PPCA_SOLVE4=$v config 4', round(j['ms_per_step'],2), 'ms per EM iteration')"
+done; done > $OUT/solve4_ab.log 2>&1
+for k in 20 32 48 64; do tools/s4bench/s4bench $k 1000000 | grep " ms"; done > $OUT/s4bench.log 2>&1
 python tools/time_passes.py 4000000 256 10 2>&1 | grep -v amdgpu.ids > $OUT/passes.log
 PPCA_LLK8=0 python tools/time_passes.py 4000000 256 10 2>&1 | grep -v amdgpu.ids | grep -i llk > $OUT/passes_llk2.log
 python tools/time_passes.py 2000000 200 16 2>&1 | grep -v amdgpu.ids > $OUT/passes_d200_k16.log
