@@ -31,13 +31,13 @@
 namespace ppca {
 #ifdef S4_TIMING  // tools/s4bench: cycles per phase, summed over the groups of wave 0 of every workgroup; [15] = groups counted
 __device__ unsigned long long s4_dbg[16];
-#define S4_STAMP(p)                                                                            \
-    do {                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                          \
-        if (wave == 0 && lane == 0) atomicAdd(&s4_dbg[p], now_ - stamp_);                      \
-        stamp_ = __builtin_amdgcn_s_memtime();                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
+#define S4_STAMP(p)                                                      \
+    do { /* (sums stay in registers: an atomic per stamp is a vector-memory operation the kernel's explicit vmcnt waits would wait for) */ \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        tacc_[p] += now_ - stamp_;                                       \
+        stamp_ = __builtin_amdgcn_s_memtime();                           \
+        __builtin_amdgcn_sched_barrier(0);                               \
     } while (0)
 #else
 #define S4_STAMP(p)
@@ -198,13 +198,16 @@ __global__ __launch_bounds__(64 * s4_waves(NB)) void solve4_kernel(SolveArgs a) 
         if (first < ngroups) request(first);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // (vmcnt(0): see the note at the group's first store -- no load is pending at the top of the loop on either path)
     }
+#ifdef S4_TIMING
+    unsigned long long tacc_[16] = {0};
+#endif
     for (int64_t grp = (int64_t)blockIdx.x * W + wave; grp < ngroups; grp += gstride) {
         asm volatile("" : "+v"(lane));  // (per-lane LDS addresses are recomputed per group instead of being parked across it)
         const int l15 = lane & 15, l4 = lane >> 4;
         const int64_t i0 = grp * NS;
 #ifdef S4_TIMING
         unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-        if (wave == 0 && lane == 0) atomicAdd(&s4_dbg[15], 1ull);
+        tacc_[15] += 1ull;
 #endif
         // ---- the group's LDS image: padding, b, the lower triangle of M = G + s2 I
         if (k < N) {
@@ -534,6 +537,10 @@ __global__ __launch_bounds__(64 * s4_waves(NB)) void solve4_kernel(SolveArgs a) 
         }
         S4_STAMP(7);
     }
+#ifdef S4_TIMING
+    if (wave == 0 && lane == 0)
+        for (int p = 0; p < 16; ++p) atomicAdd(&s4_dbg[p], tacc_[p]);
+#endif
 }
 
 template <int NB, bool EM>
