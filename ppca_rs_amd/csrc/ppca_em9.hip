@@ -480,9 +480,18 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     // =============================================================== front role
     if (E9_FRONT_PRIO) __builtin_amdgcn_s_setprio(E9_FRONT_PRIO);
     unsigned fbar_target = 0u;
-    d4_t accX[RT];
+    // cross / sumx accumulators of P4a on v_mfma_f64_4x4x4 (four independent 4 x 4 x 4 blocks per instruction: block b = lane bits
+    // 2-3; A[i][k] in lane 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane 16 i + 4 b + j -- probed on the part,
+    // tools/mfma_peak).  That instruction issues every 17.3 cycles for 512 flop (72.8 TFLOP/s, profiles/r04/mfma_peak.txt) where
+    // v_mfma_f64_16x16x4 takes 105 for 2 048 (48): the same x~ operand registers, the K + 1 columns as groups of 4.
+    // (b = X~ C of P2 the same way measured SLOWER, 87.5 against 100.7 it/s: its B operands come from global memory -- three
+    //  loads per k-step instead of one.)
+    constexpr int NCG = (K + 1 + 3) / 4;
+    double accX[RT][NCG];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) accX[r] = d4_t{0, 0, 0, 0};
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) accX[r][c] = 0.0;
     const double inv_s2_k = 1.0 / s2_k;
     double xr[RPW][4];
     const int64_t nleft = n - tile_begin * B;
@@ -906,12 +915,16 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #define E9_P4A_AHEAD 1  // k-steps the LDS operands are requested ahead of their MFMAs (measured: 2 and 3 change nothing -- 95.9 / 95.8 / 95.4 it/s -- and cost registers)
 #endif
             constexpr int AH = E9_P4A_AHEAD, NB3 = AH + 1;
-            double bzb[NB3], axb[NB3][RT];
+            double bzb[NB3][NCG], axb[NB3][RT];
             const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile + 1);
+            // k = sample 4 s + l4 of the step; A: x~[sample][dim 16 r + (lane & 15)] (rows 4 b + i of block b: the operand the
+            // 16x16x4 form read); B: [wz | w][sample][column 4 c + (lane & 3)], the same for the four blocks
+            const int j4 = lane & 3;
 #pragma unroll
             for (int s0 = 0; s0 < AH; ++s0) {
                 const int smp = 4 * s0 + l4;
-                bzb[s0] = Gcur[smp * WS + 16 * NTP + l15];
+#pragma unroll
+                for (int c = 0; c < NCG; ++c) bzb[s0][c] = Gcur[smp * WS + 16 * NTP + 4 * c + j4];
 #pragma unroll
                 for (int r = 0; r < RT; ++r) axb[s0][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
             }
@@ -920,13 +933,17 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 if (s < RPW) load_row(trs, tile + 1, s);  // unconditional (rows past the end read as zeros)
                 if (s + AH < 8) {
                     const int smp = 4 * (s + AH) + l4;
-                    bzb[(s + AH) % NB3] = Gcur[smp * WS + 16 * NTP + l15];
+#pragma unroll
+                    for (int c = 0; c < NCG; ++c) bzb[(s + AH) % NB3][c] = Gcur[smp * WS + 16 * NTP + 4 * c + j4];
 #pragma unroll
                     for (int r = 0; r < RT; ++r) axb[(s + AH) % NB3][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s % NB3][r], bzb[s % NB3], accX[r]);
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < NCG; ++c)
+                        accX[r][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(axb[s % NB3][r], bzb[s % NB3][c], accX[r][c], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -982,14 +999,16 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+        for (int r = 0; r < RT; ++r) {
+            const int dim = DW * wave + 16 * r + 4 * ((lane >> 2) & 3) + l4;  // D[i][j] of block b: lane 16 i + 4 b + j
+            if (dim >= d) continue;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int dim = DW * wave + 16 * r + l4 + 4 * q;  // C/D row of v_mfma_f64_16x16x4
-                if (dim >= d) continue;
-                if (l15 < K) out[L.cross + (int64_t)dim * K + l15] = accX[r][q];
-                else if (l15 == K) out[L.sumx + dim] = accX[r][q];
+            for (int c = 0; c < NCG; ++c) {
+                const int col = 4 * c + (lane & 3);
+                if (col < K) out[L.cross + (int64_t)dim * K + col] = accX[r][c];
+                else if (col == K) out[L.sumx + dim] = accX[r][c];
             }
+        }
     }
 }
 
