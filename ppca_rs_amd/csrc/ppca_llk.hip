@@ -487,20 +487,32 @@ __global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
     };
     auto contract_tile = [&](int lane, int slot) {
         const int l15 = lane & 15, l4 = lane >> 4;
-        const int colb = (l15 < K) ? l15 : K;
-        d4_t accb = d4_t{0, 0, 0, 0};
+        // b = X~ C on v_mfma_f64_4x4x4 (four independent 4 x 4 x 4 blocks per instruction: block b = lane bits 2-3 = samples
+        // 4 b .. 4 b + 3 of the row tile; A[i][k] in lane 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane
+        // 16 i + 4 b + j).  The part issues it every 17.3 cycles for 512 flop against 105 for the 2 048 of v_mfma_f64_16x16x4
+        // (profiles/r04/mfma_peak.txt), and K = 10 columns are three groups of 4 instead of one padded tile of 16; the A operand
+        // is the one the 16x16x4 form read, the B operand three LDS reads per k-step (the same address in the four blocks).
+        constexpr int NCB = (K + 3) / 4;
+        double accb[NCB];
+        int ccol[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            accb[c] = 0.0;
+            ccol[c] = 4 * c + (lane & 3) < K ? 4 * c + (lane & 3) : K;  // (column K of the tile of C is zero)
+        }
         const double *xrow = Xs + (16 * rtb + l15) * XS + DPQ * kq + l4;
-        const double *cpc = Cs + (DPQ * kq + l4) * CS + colb;
+        const double *cpc = Cs + (DPQ * kq + l4) * CS;
         unsigned long long mwd[4];
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) mwd[kc] = Ms[(slot * B + 16 * rt + l15) * 4 + kc];
         {
-            constexpr int CH = 4;
-            double axb[2][CH], cbb[2][CH];
+            constexpr int CH = 2;
+            double axb[2][CH], cbb[2][CH][NCB];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 axb[0][u] = xrow[4 * u];
-                cbb[0][u] = cpc[4 * u * CS];
+#pragma unroll
+                for (int cc = 0; cc < NCB; ++cc) cbb[0][u][cc] = cpc[4 * u * CS + ccol[cc]];
             }
 #pragma unroll
             for (int c = 0; c < STEPS / CH; ++c) {
@@ -508,12 +520,16 @@ __global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
 #pragma unroll
                     for (int u = 0; u < CH; ++u) {
                         axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
-                        cbb[(c + 1) & 1][u] = cpc[4 * ((c + 1) * CH + u) * CS];
+#pragma unroll
+                        for (int cc = 0; cc < NCB; ++cc) cbb[(c + 1) & 1][u][cc] = cpc[4 * ((c + 1) * CH + u) * CS + ccol[cc]];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < CH; ++u) accb = mfma(axb[c & 1][u], cbb[c & 1][u], accb);
+                for (int u = 0; u < CH; ++u)
+#pragma unroll
+                    for (int cc = 0; cc < NCB; ++cc)
+                        accb[cc] = __builtin_amdgcn_mfma_f64_4x4x4f64(axb[c & 1][u], cbb[c & 1][u][cc], accb[cc], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -545,11 +561,14 @@ __global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) Gs[(slot * B + 16 * rt + 4 * l4 + r) * GS + 16 * ct + l15] = v[r] * qs;
         }
+        {   // the four K-split partials of b, summed by the solver in a fixed order
+            const int row = slot * B + 16 * rtb + 4 * ((lane >> 2) & 3) + l4;  // D[i][j] of block b: lane 16 i + 4 b + j
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // the four K-split partials of b, summed by the solver in a fixed order
-            const int row = slot * B + 16 * rtb + l4 + 4 * r;
-            if (kq == 0) Gs[row * GS + 16 * NTP + l15] = accb[r];
-            else B1[((kq - 1) * 2 * B + row) * BS + l15] = accb[r];
+            for (int c = 0; c < NCB; ++c) {
+                const int col = 4 * c + (lane & 3);
+                if (kq == 0) Gs[row * GS + 16 * NTP + col] = accb[c];
+                else B1[((kq - 1) * 2 * B + row) * BS + col] = accb[c];
+            }
         }
     };
 
