@@ -427,9 +427,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     __syncthreads();
 
-    d4_t accX[RT];
+    // cross accumulators on v_mfma_f64_4x4x4 (four 4 x 4 x 4 blocks per instruction: block b = lane bits 2-3; A[i][k] in lane
+    // 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane 16 i + 4 b + j): one wave issues it every 18 cycles for 512 flop
+    // where v_mfma_f64_16x16x4 takes 142 for 2 048 (profiles/r04/mfma_peak.txt); the x~ operand registers are the same
+    constexpr int NCG = (K + 3) / 4;
+    double accX[RT][NCG];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) accX[r] = d4_t{0, 0, 0, 0};
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) accX[r][c] = 0.0;
     const double inv_s2_k = 1.0 / s2_k;
     double xr[RPW][4];
     const int64_t nleft = n - tile_begin * B;
@@ -798,10 +804,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ------------------------------------------------------------ P4a: cross += X~^T [wz]; the rows leave for HBM
         // behind the MFMAs: 16-byte pieces of the compact rows (column c of a row: wP for c < K', then wz, w, zeros)
         {
-            double bzb[2], axb[2][RT];
+            double bzb[2][NCG], axb[2][RT];
             p.Mb[tile * 256 + 64 * wave + lane] = Mb[64 * wave + lane];  // (ahead of the row loads: nothing here may wait for them)
             const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile + 1);
-            bzb[0] = Ws[l4 * WS + KP + l15];  // (columns past K of the tile: stale values, in output columns nobody stores)
+            const int j4 = lane & 3;
+#pragma unroll
+            for (int c = 0; c < NCG; ++c) bzb[0][c] = Ws[l4 * WS + KP + 4 * c + j4];  // (columns past K of the tile: stale values, in output columns nobody stores)
 #pragma unroll
             for (int r = 0; r < RT; ++r) axb[0][r] = Xs[l4 * XS + DW * wave + 16 * r + l15];
             const int64_t row0 = tile * B;
@@ -831,13 +839,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (s < RPW) load_row(trs, s);  // unconditional (rows past the end read as zeros)
                 if (s + 1 < 8) {
                     const int smp = 4 * (s + 1) + l4;
-                    bzb[(s + 1) & 1] = Ws[smp * WS + KP + l15];
+#pragma unroll
+                    for (int c = 0; c < NCG; ++c) bzb[(s + 1) & 1][c] = Ws[smp * WS + KP + 4 * c + j4];
 #pragma unroll
                     for (int r = 0; r < RT; ++r) axb[(s + 1) & 1][r] = Xs[smp * XS + DW * wave + 16 * r + l15];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < RT; ++r) accX[r] = mfma(axb[s & 1][r], bzb[s & 1], accX[r]);
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < NCG; ++c)
+                        accX[r][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(axb[s & 1][r], bzb[s & 1][c], accX[r][c], 0, 0, 0);
 #pragma unroll
                 for (int u = s; u < CPT; u += 8) copy_piece(u);
                 __builtin_amdgcn_sched_barrier(0);
@@ -897,13 +909,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+        for (int r = 0; r < RT; ++r) {
+            const int dim = DW * wave + 16 * r + 4 * ((lane >> 2) & 3) + l4;  // D[i][j] of block b: lane 16 i + 4 b + j
+            if (dim >= d) continue;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int dim = DW * wave + 16 * r + l4 + 4 * q;  // C/D row of v_mfma_f64_16x16x4
-                if (dim >= d) continue;
-                if (l15 < K) out[L.cross + (int64_t)dim * K + l15] = accX[r][q];
+            for (int c = 0; c < NCG; ++c) {
+                const int col = 4 * c + (lane & 3);
+                if (col < K) out[L.cross + (int64_t)dim * K + col] = accX[r][c];
             }
+        }
     }
 }
 

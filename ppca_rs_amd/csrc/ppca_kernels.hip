@@ -133,6 +133,11 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     __syncthreads();
     if (j == 0) qflag[t] = bad;
     if (j == 0 && t == 0) qflag[8] = qflag[9] = 0;  // the pass's run-again flag and the W-side verdict (wguard_kernel)
+    if constexpr (K <= FUSED_MAX_K) {  // tiles this state size does not have: ppca_em_last_guard reads the first four flags whatever
+        // the k of the last pass, and the buffer may have held a larger model's (or the two-kernel pass's) flags
+        if (j == 0 && t == 0)
+            for (int u = (K * (K + 1) / 2 + 15) / 16; u < 8; ++u) qflag[u] = 0;
+    }
     // zero-padded copy of C: ppca_em9.hip (and em8's -DE8_C_GLOBAL experiment) read the B operands of b = X~ C from it.  Only
     // in the layout of fused_qtab_layout (k <= FUSED_MAX_K: the copy sits behind the largest table); the callers with their
     // own, exactly sized tables (ppca_em16.hip's, k = 11..16) have no room behind them -- round 4 found that the hard way:

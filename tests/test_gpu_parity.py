@@ -648,6 +648,26 @@ def test_generic_pipeline_matches_oracle(P, oracle, n, d, k, mp, block):
     assert _rel(dev_diag, diag) < 1e-7
 
 
+def test_last_guard_after_a_larger_model(P, oracle):
+    """ppca_em_last_guard reads the first four Gram-guard flags whatever the state size of the last pass: after a pass with more
+    packed-column tiles (k = 10: four; the two-kernel pass and the split pipeline share the buffer) a k = 1 pass must not report
+    the other model's flags (found by running the split-pipeline tests right before the steady-state tests of k = 1, 4, 7)."""
+    from ppca_rs_amd import _lib
+
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(77)
+    for k_big, d_big in ((10, 256), (16, 200), (20, 70)):
+        xb, _, _ = oracle.synth(300, d_big, k_big, 0.2, 60 + k_big)
+        cb = rng.standard_normal((d_big, k_big))
+        cb[:, 0] *= 1e8  # a model whose Gram guard trips (rows of C spanning 1e8): its flags stay in the buffer
+        P.PPCAModel(1.0, cb, np.zeros(d_big)).iterate(P.Dataset(xb))
+        for k, d in ((1, 64), (4, 200), (7, 255)):
+            x, _, _ = oracle.synth(500, d, k, 0.3, 80 + k)
+            m = P.PPCAModel(0.7, 0.6 * rng.standard_normal((d, k)), 0.2 * rng.standard_normal(d))
+            m.iterate(P.Dataset(x))
+            assert ctx.last_guard() == (0, 0), (k_big, k)
+
+
 def test_two_ranks_on_one_gpu_match_single_rank(P, tmp_path):
     """The N > 1 path of bench.py (row shards, per-rank pass, all-reduce of the statistics buffer on the
     launch stream, replicated finalisation) with two ranks sharing this GPU over gloo: the model after
