@@ -659,7 +659,7 @@ def test_last_guard_after_a_larger_model(P, oracle):
     for k_big, d_big in ((10, 256), (16, 200), (20, 70)):
         xb, _, _ = oracle.synth(300, d_big, k_big, 0.2, 60 + k_big)
         cb = rng.standard_normal((d_big, k_big))
-        cb[:, 0] *= 1e8  # a model whose Gram guard trips (rows of C spanning 1e8): its flags stay in the buffer
+        cb[0] *= 1e8  # a model whose Gram guard trips (rows of C spanning 1e8): its flags stay in the buffer
         P.PPCAModel(1.0, cb, np.zeros(d_big)).iterate(P.Dataset(xb))
         for k, d in ((1, 64), (4, 200), (7, 255)):
             x, _, _ = oracle.synth(500, d, k, 0.3, 80 + k)
