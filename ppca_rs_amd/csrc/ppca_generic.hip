@@ -421,15 +421,21 @@ __global__ __launch_bounds__(256) void gen_prep_kernel(const double *X, int64_t 
     d4g_t acc[NT];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) acc[tt] = d4g_t{0, 0, 0, 0};
-    for (int j0 = 0; j0 < dpad; j0 += 64) {
-        const int j = j0 + lane;
-        const double mu = j < d ? mean[j] : 0.0;
-        double v[16];
+    // the rows of dimension block j0 + 64 are requested as soon as those of block j0 sit in LDS (round 4: the loop paid one
+    // global-memory latency per block with nothing of its own to cover it)
+    double v[16];
+    auto load_block = [&](int jb) {
+        const int j = jb + lane;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int64_t row = i0 + 16 * wave + rr;
             v[rr] = (row < n && j < d) ? X[row * ldx + j] : __builtin_nan("");
         }
+    };
+    load_block(0);
+    for (int j0 = 0; j0 < dpad; j0 += 64) {
+        const int j = j0 + lane;
+        const double mu = j < d ? mean[j] : 0.0;
         auto load_c = [&](int h) {  // columns 16 CT h .. of the block's rows of C (zero past d and past k)
             for (int idx = t; idx < 64 * 16 * CT; idx += 256) {
                 const int jj = idx / (16 * CT), a = 16 * CT * h + idx - jj * (16 * CT);
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(256) void gen_prep_kernel(const double *X, int64_t 
             smc[rr] += fin ? 1.0 : 0.0;
         }
         __syncthreads();
+        if (j0 + 64 < dpad) load_block(j0 + 64);
         if (want_bytes) {
             const int r = t >> 2, q = t & 3;
             union { unsigned char b[16]; gi4_t vv; } u;
