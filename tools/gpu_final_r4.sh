@@ -6,6 +6,9 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/r4f
 mkdir -p $OUT $GRAFT_REPO_ROOT/profiles/r04
 cd /tmp && export TMPDIR=/tmp
 COMMIT=$(cat $GRAFT_REPO_ROOT/tools/commit_stamp.txt 2>/dev/null)
+# the two harnesses are git-ignored binaries: built here when the tree arrived without them
+[ -x $GRAFT_REPO_ROOT/tools/mfma_peak/mfma_peak ] || hipcc --offload-arch=gfx950 -O3 -w $GRAFT_REPO_ROOT/tools/mfma_peak/mfma_peak.hip -o $GRAFT_REPO_ROOT/tools/mfma_peak/mfma_peak
+[ -x $GRAFT_REPO_ROOT/tools/s4bench/s4bench ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -I $GRAFT_REPO_ROOT/ppca_rs_amd/csrc $GRAFT_REPO_ROOT/tools/s4bench/s4bench.hip -o $GRAFT_REPO_ROOT/tools/s4bench/s4bench
 # what the part sustains on nothing but MFMAs (cited beside the nominal peak by bench.py)
 $GRAFT_REPO_ROOT/tools/mfma_peak/mfma_peak "$COMMIT" > $OUT/mfma_peak.txt 2>&1
 tail -1 $OUT/mfma_peak.txt > $GRAFT_REPO_ROOT/profiles/r04/mfma_peak.json
