@@ -40,6 +40,12 @@ constexpr int E9_FLUSH_GROUPS = 100;
 #ifndef E9_FRONT_PRIO
 #define E9_FRONT_PRIO 0
 #endif
+#ifndef E9_B_BACK
+#define E9_B_BACK 0  // 1: b = X~ C of a tile is computed by the BACK role (two more counters: x~ staged -> back, b written -> solver).
+                     // Measured (round 4, gpurun_out/r4bb): correct, 85.6 against 100.8 EM it/s -- b of tile t can only be written once the
+                     // back role has cut tile t - 2 (the buffer of its parity), which puts it behind the back role's own iteration and
+                     // the front's solver waits for it.
+#endif
 #ifndef E9_GS_PAD
 #define E9_GS_PAD 18  // row stride of [G | b] / W rows = 16 NTP + 18 doubles: even, so that the solver's lane-per-sample accesses
                       // pair up into 16-byte LDS operations that spread over all banks (measured: 17 costs 2 %)
@@ -83,7 +89,7 @@ struct Cfg9 {
     static constexpr int OFF_P1 = OFF_P0 + PLANE_BYTES / 8;  // ... and of its second
     static constexpr int OFF_E = OFF_P1 + PLANE_BYTES / 8;  // column exponents (NCOL ints), flags
     static constexpr int OFF_BAR = OFF_E + NCOL / 2 + 4;  // counters: front barrier, back barrier, tiles digitised, violation stamp
-    static constexpr int OFF_MU = OFF_BAR + 4;            // the mean (DP doubles, zero past d): re-read by the staging of every tile
+    static constexpr int OFF_MU = OFF_BAR + (E9_B_BACK ? 5 : 4);  // (E9_B_BACK: ten counters) the mean (DP doubles, zero past d): re-read by the staging of every tile
     static constexpr int OFF_K = OFF_MU + DP;             // model scalars: sigma^2, 1 / sigma^2, ln sigma (re-read per tile)
     static constexpr int OFF_EB = OFF_K + 4;              // rounding bounds of the cut, per column (wguard_kernel)
     static constexpr int OFF_XT = OFF_EB + NCOL;          // by-products of the solve (quad, |z|^2, det M) per sample, two tile parities
@@ -147,6 +153,9 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     int *Ex = reinterpret_cast<int *>(sm + cfg::OFF_E);
     unsigned *ctr = reinterpret_cast<unsigned *>(sm + cfg::OFF_BAR);
     unsigned *fbar = ctr, *bbar = ctr + 1, *digdone = ctr + 2, *vstamp = ctr + 3, *wready = ctr + 4, *itdone = ctr + 5, *cbar = ctr + 6;
+    unsigned *xready = ctr + 7, *bdone = ctr + 8;  // (E9_B_BACK) 4 (t + 1): x~ of tile t staged; 4 (t + 1): b of tile t written
+    (void)xready;
+    (void)bdone;
 
     if (p.qflag) {  // qprep's dynamic-range guard: the fp64-Gram pass_kernel runs instead
         int unsafe = 0;
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #ifdef E9_ONLY_BACK
     for (int idx = tid; idx < 2 * B * GS; idx += 512) Gs[idx] = 1.0;  // (something finite for the back role to cut)
 #endif
-    if (tid < 8) ctr[tid] = 0u;
+    if (tid < (E9_B_BACK ? 10 : 8)) ctr[tid] = 0u;
     if (tid < NCOL) sm[cfg::OFF_EB + tid] = 0.0;
     if (tid == 0) {
         sm[cfg::OFF_K] = s2_k;
@@ -199,6 +208,49 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     if (front) return;
 #endif
 
+#if E9_B_BACK
+    // b = X~ C of tile trel (K-split in two halves: wave wv -> row tile wv & 1, half wv >> 1), run by the BACK role's waves: the
+    // front chain is what the launch waits for, the back role has the slack (front alone 9.1 ms, back alone 4.0)
+    auto b_product = [&](int lane, int trel, int wv) {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int colb = (l15 < K) ? l15 : K;
+        const int rt = wv & 1, kq = wv >> 1;
+        double *Gt = Gs + (trel & 1) * B * GS;
+        d4_t accb = d4_t{0, 0, 0, 0};
+        const double *xrow = Xs + (16 * rt + l15) * XS + DPS * kq + l4;
+        constexpr int CH = 2, NCH = STEPS / CH;  // (the back role keeps 160 accumulator registers: a shorter look-ahead than the front had)
+        const double *cg = p.cpad + (DPS * kq + l4) * CS + colb;
+        double axb[2][CH], cbb[3][CH];
+#pragma unroll
+        for (int c0 = 0; c0 < 2; ++c0)
+#pragma unroll
+            for (int u = 0; u < CH; ++u) cbb[c0][u] = cg[4 * (c0 * CH + u) * CS];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) axb[0][u] = xrow[4 * u];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
+            }
+            if (c + 2 < NCH) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) cbb[(c + 2) % 3][u] = cg[4 * ((c + 2) * CH + u) * CS];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) accb = mfma(axb[c & 1][u], cbb[c % 3][u], accb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (kq == 0) Gt[(16 * rt + l4 + 4 * r) * GS + 16 * NTP + l15] = accb[r];
+            else if (l15 < K + 1) B1[(16 * rt + l4 + 4 * r) * BS + l15] = accb[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(bdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+#endif
     if (!front) {
         // =========================================================== back role: P4b on the int8 MFMA
         typedef double acc_t;
@@ -414,6 +466,17 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
             });
         };
 
+#if E9_B_BACK
+        const int ntl = (int)(tile_end - tile_begin);
+        if (ntl > 0) {
+            wait_counter(xready, 4u);
+            b_product(lane_entry, 0, wave);
+        }
+        if (ntl > 1) {
+            wait_counter(xready, 8u);
+            b_product(lane_entry, 1, wave);
+        }
+#endif
         for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
             int lane = lane_entry;
             asm volatile("" : "+v"(lane));
@@ -438,6 +501,12 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 if (!viol) {  // every back wave has read the tile's rows for the last time: the front may overwrite them
                     if (lane_entry == 0) __hip_atomic_fetch_add(digdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     rows_win += B;
+#if E9_B_BACK
+                    if (rel + 2 < ntl) {  // the buffer of this parity is free: b of the tile that takes it next, BEFORE the contraction
+                        wait_counter(xready, 4u * (unsigned)(rel + 3));
+                        b_product(lane, rel + 2, wave);
+                    }
+#endif
                 }
                 const bool con = pending || (!viol && last);
                 if (con) {
@@ -617,6 +686,9 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         stage_tile(tile_begin, lane_entry);
     }
     role_barrier(fbar, fbar_target, lane_entry);
+#if E9_B_BACK
+    if (lane_entry == 0) __hip_atomic_fetch_add(xready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 
     // z of a solved sample lives in the row's free slots until the columns of its tile are formed: the unused columns of
     // the b partial, the pad, then the unused packed-column slots behind K'
@@ -656,8 +728,13 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         if (cur) {
             const int rt = wave & 1, kq = wave >> 1;
             const int si = 16 * rt + l15;
+#if !E9_B_BACK
             d4_t accb = d4_t{0, 0, 0, 0};
             const double *xrow = Xs + si * XS + DPS * kq + l4;
+#else
+            (void)si;
+            (void)kq;
+#endif
             // the count of tiles the back role has cut, requested HERE and looked at where [G | b] is stored: by then it is
             // almost always enough, and the poll (an LDS round trip behind everything this wave has queued: ~0.7 k cycles per
             // tile in the phase table) is skipped
@@ -712,6 +789,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 group(qbB, false);  // digits {5,4}
                 load_pair(qbB, 0);
             }
+#if !E9_B_BACK
             {
                 // EXPERIMENT: the B operands from the zero-padded copy of C in global memory (L1 / L2) instead of the LDS tile
                 // (would free 22.5 KB of LDS), requested two chunks of four k-steps ahead
@@ -740,6 +818,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#endif
             group(qbA, false);  // digits {3,2}
             group(qbB, false);  // digits {1,0}
             E9_FINE(0)
@@ -755,11 +834,13 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                         Gcur[(16 * rt2 + 4 * l4 + r) * GS + 16 * wave + l15] = v[rt2][r] * qs;  // (sample-major: the solver's loads pair up into 16-byte reads; entry-major measured 2 % slower)
             }
             // the two K-split partials of b are summed by the solver in a fixed order (p0 + p1)
+#if !E9_B_BACK
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (kq == 0) Gcur[(16 * rt + l4 + 4 * r) * GS + 16 * NTP + l15] = accb[r];
                 else if (l15 < K + 1) B1[(16 * rt + l4 + 4 * r) * BS + l15] = accb[r];
             }
+#endif
         }
         E9_FINE(2)
         role_barrier(fbar, fbar_target, lane_entry);
@@ -794,6 +875,9 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #pragma unroll
                     for (int a = 0; a < K; ++a) z[a] = s2 + (double)a;
 #else
+#if E9_B_BACK
+                    wait_counter(bdone, 4u * (unsigned)(rel + 1));  // the back role has written b of this tile
+#endif
                     fac.load([&](int e) { return g0[e]; }, s2);
 #pragma unroll
                     for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a] + b1[a];
@@ -956,6 +1040,9 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         stage_tile(tile + 1, lane);
         E9_FINE(13)
         role_barrier(fbar, fbar_target, lane_entry);
+#if E9_B_BACK
+        if (lane_entry == 0) __hip_atomic_fetch_add(xready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         E9_FINE(14)
     }
 #ifdef PPCA_PHASE_TIMING
