@@ -442,16 +442,22 @@ def main() -> None:
             # What the step EXECUTED (never K x N x the EM flops: the component passes gather only the rows whose weight is not
             # negligible -- the device-side row counts of the last timed step): K log-likelihood sweeps over every row + the
             # gathered EM passes
-            used = (C.c_int64 * nm)()
-            _lib.check(_lib.lib().ppca_mix_last_rows_used(ctx.handle, used, nm))
-            rows_gathered = [int(v) for v in used]
+            if em._one_call:
+                used = (C.c_int64 * nm)()
+                _lib.check(_lib.lib().ppca_mix_last_rows_used(ctx.handle, used, nm))
+                rows_gathered = [int(v) for v in used]
+            else:  # the step composed from the building blocks (--collective torch / gloo): ppca_mix_component_stats' own counts
+                rows_gathered = [int(v) for v in em.backend.rows_used]
             flops_step = (nm * rows_local * algorithmic_flops_llk_per_sample(k, m_obs)
                           + sum(rows_gathered) * algorithmic_flops_per_sample(d, k, m_obs))
             flops_reference = nm * rows_local * (algorithmic_flops_llk_per_sample(k, m_obs) + algorithmic_flops_per_sample(d, k, m_obs))
             tflops, gbs = flops_step / t_step / 1e12, bytes_step / t_step / 1e9
             fp64_bound = False  # the mixture is reported against the ONE-pass byte figure (X read once per iteration)
-            kernel_name = (f"one mixture EM iteration = {nm} llk2_kernel<{k}> sweeps + {nm} gathered em9_kernel<{k}, true> passes + "
-                           "finalisations (timed as one region: ONE C-ABI call)")
+            llk_kernel = "llk2_kernel" if os.environ.get("PPCA_LLK8") == "0" else "llk8_kernel"
+            em_kernel = ("pass_kernel" if os.environ.get("PPCA_EM8") == "0" else
+                         "em8_kernel" if os.environ.get("PPCA_EM9") == "0" else "em9_kernel")
+            kernel_name = (f"one mixture EM iteration = {nm} {llk_kernel}<{k}> sweeps + {nm} gathered {em_kernel}<{k}, true> passes + "
+                           "finalisations (timed as one region" + (": ONE C-ABI call)" if em._one_call else ", composed from the C-ABI building blocks)"))
             kern_avg_ms, launches_rep = 1e3 * t_step, args.steps
             traffic, traffic_src = None, None
         else:

@@ -803,15 +803,16 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         {
             const double tl = (double)((n + FUSED_TILE - 1) / FUSED_TILE) / grid;
-            static const char *fn[16] = {"P2", "wait-back", "stores", "barrier", "P3-load", "barrier", "factor", "solve", "columns", "scalars",
-                                         "wg-barrier", "P4a", "barrier", "staging", "barrier", "-"};
+            // (em9: "P2" = the Gram's last two digit pairs, "b-loop" = b = X~ C, "gram-1" = mask bytes + the first two digit pairs)
+            static const char *fn[16] = {"P2", "wait-back", "stores", "barrier", "b-loop", "barrier", "factor", "solve", "columns", "scalars",
+                                         "wg-barrier", "P4a", "barrier", "staging", "barrier", "gram-1"};
             static const char *bn[16] = {"wg-barrier", "digitise", "barrier", "contract", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"};
             for (int w = 0; w < 8; ++w) {
                 double tw[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 for (int g = 0; g < grid; ++g)
                     for (int i = 0; i < 16; ++i) tw[i] += h[(size_t)grid * 16 + ((size_t)g * 8 + w) * 16 + i] / grid;
                 fprintf(stderr, "[em8 wave %d cycles/tile]", w);
-                for (int i = 0; i < (w < 4 ? 15 : 4); ++i) fprintf(stderr, " %s %.0f", w < 4 ? fn[i] : bn[i], tw[i] / tl);
+                for (int i = 0; i < (w < 4 ? 16 : 4); ++i) fprintf(stderr, " %s %.0f", w < 4 ? fn[i] : bn[i], tw[i] / tl);
                 fprintf(stderr, "\n");
             }
         }

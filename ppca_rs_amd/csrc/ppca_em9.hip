@@ -40,11 +40,31 @@ constexpr int E9_FLUSH_GROUPS = 100;
 #ifndef E9_FRONT_PRIO
 #define E9_FRONT_PRIO 0
 #endif
-#ifndef E9_B_BACK
-#define E9_B_BACK 0  // 1: b = X~ C of a tile is computed by the BACK role (two more counters: x~ staged -> back, b written -> solver).
-                     // Measured (round 4, gpurun_out/r4bb): correct, 85.6 against 100.8 EM it/s -- b of tile t can only be written once the
-                     // back role has cut tile t - 2 (the buffer of its parity), which puts it behind the back role's own iteration and
-                     // the front's solver waits for it.
+#ifndef E9_B444
+#define E9_B444 0  // 1: b = X~ C on v_mfma_f64_4x4x4 with the dimension and sample groups in the instruction's four blocks (round 5
+                   // experiment, parity-green).  Measured (gpurun_out/r5ab1, r5ab2, r5t1, r5t2; profiles/r05/README.md): 100.0 against
+                   // 100.7 EM it/s for the 16 x 16 x 4 form -- the loop's 96 MFMAs of 17 cycles take 2.84 k cycles per tile against
+                   // 2.70 k for 32 of 64: the 48 loads of C per wave and tile queue behind the Gram's digit-table loads (one in-order
+                   // vmcnt), deeper look-ahead changes nothing (E9_LAC=6: 99.9).  With the C operands from LDS (timing experiment
+                   // E9_EXP_CLDS, results wrong) the loop takes 2.22 k and the launch 104.8 it/s -- but LDS has 1.7 KB free where 20 KB are
+                   // needed, and what can be reclaimed (66-column digit planes 6.3, mean 2, row stride 2, second b partial 2.8) stops at 15.
+#endif
+#ifndef E9_B_EARLYC
+#define E9_B_EARLYC 1  // the first steps of C operands requested before the Gram's digit pairs (their L2 latency under the integer MFMAs)
+#endif
+#ifndef E9_X_AUX
+#define E9_X_AUX 0  // cache policy of the row loads of X (2 = nt: L2-served, the rows are read once and would only push C out of the 32 KB
+                    // L1).  Measured: + 0.5 % (100.7-101.0 against 100.1-100.8 it/s), inside the box-to-box spread; not adopted
+#endif
+#ifndef E9_Q_AUX
+#define E9_Q_AUX 0  // ... and of the Gram's digit table (128 KB per tile and workgroup).  Measured with 2 (nt): 90.0 against 100.7 it/s
+#endif
+#ifndef E9_LAC
+#define E9_LAC 4
+#endif
+#ifndef E9_QB_EARLY
+#define E9_QB_EARLY 0  // 1: the second digit pair {5,4} requested with {7,6} during the previous tile's P4a (round 5 experiment): the
+                       // first half of the Gram 2.40 -> 2.12 k cycles per tile, the b loop 2.70 -> 2.87 k, the launch 100.7 against 100.8 it/s
 #endif
 #ifndef E9_GS_PAD
 #define E9_GS_PAD 18  // row stride of [G | b] / W rows = 16 NTP + 18 doubles: even, so that the solver's lane-per-sample accesses
@@ -89,7 +109,7 @@ struct Cfg9 {
     static constexpr int OFF_P1 = OFF_P0 + PLANE_BYTES / 8;  // ... and of its second
     static constexpr int OFF_E = OFF_P1 + PLANE_BYTES / 8;  // column exponents (NCOL ints), flags
     static constexpr int OFF_BAR = OFF_E + NCOL / 2 + 4;  // counters: front barrier, back barrier, tiles digitised, violation stamp
-    static constexpr int OFF_MU = OFF_BAR + (E9_B_BACK ? 5 : 4);  // (E9_B_BACK: ten counters) the mean (DP doubles, zero past d): re-read by the staging of every tile
+    static constexpr int OFF_MU = OFF_BAR + 4;  // the mean (DP doubles, zero past d): re-read by the staging of every tile
     static constexpr int OFF_K = OFF_MU + DP;             // model scalars: sigma^2, 1 / sigma^2, ln sigma (re-read per tile)
     static constexpr int OFF_EB = OFF_K + 4;              // rounding bounds of the cut, per column (wguard_kernel)
     static constexpr int OFF_XT = OFF_EB + NCOL;          // by-products of the solve (quad, |z|^2, det M) per sample, two tile parities
@@ -153,9 +173,6 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     int *Ex = reinterpret_cast<int *>(sm + cfg::OFF_E);
     unsigned *ctr = reinterpret_cast<unsigned *>(sm + cfg::OFF_BAR);
     unsigned *fbar = ctr, *bbar = ctr + 1, *digdone = ctr + 2, *vstamp = ctr + 3, *wready = ctr + 4, *itdone = ctr + 5, *cbar = ctr + 6;
-    unsigned *xready = ctr + 7, *bdone = ctr + 8;  // (E9_B_BACK) 4 (t + 1): x~ of tile t staged; 4 (t + 1): b of tile t written
-    (void)xready;
-    (void)bdone;
 
     if (p.qflag) {  // qprep's dynamic-range guard: the fp64-Gram pass_kernel runs instead
         int unsafe = 0;
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #ifdef E9_ONLY_BACK
     for (int idx = tid; idx < 2 * B * GS; idx += 512) Gs[idx] = 1.0;  // (something finite for the back role to cut)
 #endif
-    if (tid < (E9_B_BACK ? 10 : 8)) ctr[tid] = 0u;
+    if (tid < 8) ctr[tid] = 0u;
     if (tid < NCOL) sm[cfg::OFF_EB + tid] = 0.0;
     if (tid == 0) {
         sm[cfg::OFF_K] = s2_k;
@@ -208,49 +225,6 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     if (front) return;
 #endif
 
-#if E9_B_BACK
-    // b = X~ C of tile trel (K-split in two halves: wave wv -> row tile wv & 1, half wv >> 1), run by the BACK role's waves: the
-    // front chain is what the launch waits for, the back role has the slack (front alone 9.1 ms, back alone 4.0)
-    auto b_product = [&](int lane, int trel, int wv) {
-        const int l15 = lane & 15, l4 = lane >> 4;
-        const int colb = (l15 < K) ? l15 : K;
-        const int rt = wv & 1, kq = wv >> 1;
-        double *Gt = Gs + (trel & 1) * B * GS;
-        d4_t accb = d4_t{0, 0, 0, 0};
-        const double *xrow = Xs + (16 * rt + l15) * XS + DPS * kq + l4;
-        constexpr int CH = 2, NCH = STEPS / CH;  // (the back role keeps 160 accumulator registers: a shorter look-ahead than the front had)
-        const double *cg = p.cpad + (DPS * kq + l4) * CS + colb;
-        double axb[2][CH], cbb[3][CH];
-#pragma unroll
-        for (int c0 = 0; c0 < 2; ++c0)
-#pragma unroll
-            for (int u = 0; u < CH; ++u) cbb[c0][u] = cg[4 * (c0 * CH + u) * CS];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) axb[0][u] = xrow[4 * u];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u) axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
-            }
-            if (c + 2 < NCH) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u) cbb[(c + 2) % 3][u] = cg[4 * ((c + 2) * CH + u) * CS];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) accb = mfma(axb[c & 1][u], cbb[c % 3][u], accb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (kq == 0) Gt[(16 * rt + l4 + 4 * r) * GS + 16 * NTP + l15] = accb[r];
-            else if (l15 < K + 1) B1[(16 * rt + l4 + 4 * r) * BS + l15] = accb[r];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(bdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-#endif
     if (!front) {
         // =========================================================== back role: P4b on the int8 MFMA
         typedef double acc_t;
@@ -466,17 +440,6 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
             });
         };
 
-#if E9_B_BACK
-        const int ntl = (int)(tile_end - tile_begin);
-        if (ntl > 0) {
-            wait_counter(xready, 4u);
-            b_product(lane_entry, 0, wave);
-        }
-        if (ntl > 1) {
-            wait_counter(xready, 8u);
-            b_product(lane_entry, 1, wave);
-        }
-#endif
         for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
             int lane = lane_entry;
             asm volatile("" : "+v"(lane));
@@ -501,12 +464,6 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 if (!viol) {  // every back wave has read the tile's rows for the last time: the front may overwrite them
                     if (lane_entry == 0) __hip_atomic_fetch_add(digdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     rows_win += B;
-#if E9_B_BACK
-                    if (rel + 2 < ntl) {  // the buffer of this parity is free: b of the tile that takes it next, BEFORE the contraction
-                        wait_counter(xready, 4u * (unsigned)(rel + 3));
-                        b_product(lane, rel + 2, wave);
-                    }
-#endif
                 }
                 const bool con = pending || (!viol && last);
                 if (con) {
@@ -588,7 +545,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                     const_cast<double *>(p.X + (int64_t)rows_wg[rc < 0 ? 0 : rc] * p.ldx), 0, rc < 0 ? 0 : rowbytes, 0x00020000);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, 0);
+                    const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, E9_X_AUX);
                     xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
                     xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
                 }
@@ -597,7 +554,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(trs, lane_entry * 16, (wave * RPW + r) * rowbytes + 1024 * h, 0);
+            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(trs, lane_entry * 16, (wave * RPW + r) * rowbytes + 1024 * h, E9_X_AUX);
             xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
             xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
         }
@@ -605,6 +562,10 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(p.qtab, 0, (int)qtab_bytes<K>(), 0x00020000);
     const bool gram_wave = NTP >= NF || wave < NTP;
     i4_t qbA[2][4];
+#if E9_QB_EARLY
+    i4_t qbB[2][4];  // digits {5,4} requested with {7,6} during the previous tile's P4a (round 5): requested at the top of P2 they
+                     // were ~600 cycles old when the second digit pair wanted them -- an L2 round trip is longer
+#endif
     auto load_pair = [&](i4_t(&dst)[2][4], int sl0) {
         int qbase = wave * QS * 4 * 1024;
         asm volatile("" : "+s"(qbase));
@@ -613,7 +574,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16 + kc * 1024, qbase + (sl0 + u) * 4096, 0);
+                const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane_entry * 16 + kc * 1024, qbase + (sl0 + u) * 4096, E9_Q_AUX);
                 dst[u][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
             }
     };
@@ -683,12 +644,12 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) load_row(trs, tile_begin, r);
         load_pair(qbA, 6);
+#if E9_QB_EARLY
+        load_pair(qbB, 4);
+#endif
         stage_tile(tile_begin, lane_entry);
     }
     role_barrier(fbar, fbar_target, lane_entry);
-#if E9_B_BACK
-    if (lane_entry == 0) __hip_atomic_fetch_add(xready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
 
     // z of a solved sample lives in the row's free slots until the columns of its tile are formed: the unused columns of
     // the b partial, the pad, then the unused packed-column slots behind K'
@@ -727,13 +688,13 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         // ------------------------------------------------------------ P2: [G | b] of the tile
         if (cur) {
             const int rt = wave & 1, kq = wave >> 1;
+#if E9_B444
+            constexpr int NCGB = (K + 3) / 4;  // column groups of four
+            double bsum[NCGB];
+#else
             const int si = 16 * rt + l15;
-#if !E9_B_BACK
             d4_t accb = d4_t{0, 0, 0, 0};
             const double *xrow = Xs + si * XS + DPS * kq + l4;
-#else
-            (void)si;
-            (void)kq;
 #endif
             // the count of tiles the back role has cut, requested HERE and looked at where [G | b] is stored: by then it is
             // almost always enough, and the poll (an LDS round trip behind everything this wave has queued: ~0.7 k cycles per
@@ -761,8 +722,53 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                     }
                 }
             };
+#if E9_B444
+            // (operand pointers of the b product; its first LAC steps of C are requested before the Gram's digit pairs so that
+            //  their L2 latency passes under the integer MFMAs)
+                constexpr int NQ = DPS / 8;  // steps of 8 dimensions (two blocks of four)
+                constexpr int LAC = E9_LAC, LAX = 2;  // look-ahead in steps: C (L2 latency), x~ (LDS)
+                const int j4 = lane & 3, sb = (lane >> 2) & 1, kb = (lane >> 3) & 1;
+                const double *xrow = Xs + (16 * rt + 4 * sb + j4) * XS + DPS * kq + 16 * kb + l4;
+                const __amdgpu_buffer_rsrc_t crs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.cpb), 0, CPB_DOUBLES * (int)sizeof(double), 0x00020000);
+                const int cvo = ((2 * l4 + kb) * 4 + j4) * 8;
+                // (soffset: one SGPR per 4 KB of the wave's half of the table, the rest in the instruction's 12-bit immediate -- left to
+                //  the compiler every load had its own s_add)
+                constexpr int NSO = (NQ * NCGB * 256 + 4095) / 4096;
+                int cso[NSO];
+#pragma unroll
+                for (int u = 0; u < NSO; ++u) {
+                    cso[u] = kq * (NQ * NCGB * 256) + 4096 * u;
+                    asm volatile("" : "+s"(cso[u]));
+                }
+                double accb[NCGB][2];
+#pragma unroll
+                for (int c = 0; c < NCGB; ++c) accb[c][0] = accb[c][1] = 0.0;
+                double cb[LAC + 1][NCGB], xb[LAX + 1][2];
+                auto cload = [&](auto q_tag) {
+                    constexpr int q = decltype(q_tag)::value;
+#pragma unroll
+                    for (int c = 0; c < NCGB; ++c) {
+                        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+                        const int off = (q * NCGB + c) * 256;  // (a constant once the loop is unrolled)
+#ifdef E9_EXP_CLDS  // (timing experiment, results wrong: what the loop would cost with its C operands in LDS)
+                        cb[q % (LAC + 1)][c] = Xs[(cvo + off) / 8 + kq * 4096];
+                        continue;
+#endif
+                        const u2_t v2 = __builtin_amdgcn_raw_buffer_load_b64(crs, cvo + (off & 4095), cso[off >> 12], 0);
+                        cb[q % (LAC + 1)][c] = __longlong_as_double(((long long)v2[1] << 32) | v2[0]);
+                    }
+                };
+                auto xload = [&](auto q_tag) {
+                    constexpr int q = decltype(q_tag)::value;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) xb[q % (LAX + 1)][g] = xrow[8 * g * XS + 32 * (q >> 2) + 4 * (q & 3)];
+                };
+#endif
             double qs = 0.0;
+#if !E9_QB_EARLY
             i4_t qbB[2][4];
+#endif
             {
                 unsigned long long mwd[2][4];
 #pragma unroll
@@ -770,8 +776,13 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #pragma unroll
                     for (int kc = 0; kc < 4; ++kc) mwd[rt2][kc] = Msc[(16 * rt2 + l15) * 4 + kc];
                 __builtin_amdgcn_sched_barrier(0);
+#if !E9_QB_EARLY
                 load_pair(qbB, 4);
+#endif
                 if (gram_wave) qs = p.qscale[16 * wave + l15];
+#if E9_B444 && E9_B_EARLYC
+                static_for<LAC>([&](auto q_tag) { cload(q_tag); });
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // A = mask bytes: lane (sample 16 rt2 + l15, k-chunk kc, 16 l4 .. +15 of it); 4 bits -> 4 bytes by one
                 // multiply: (x * 0x204081) & 0x01010101 puts bit i of x into byte i
@@ -789,10 +800,47 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 group(qbB, false);  // digits {5,4}
                 load_pair(qbB, 0);
             }
-#if !E9_B_BACK
+            E9_FINE(15)  // "-": mask bytes + digit pairs {7,6}, {5,4}
+#if E9_B444
             {
-                // EXPERIMENT: the B operands from the zero-padded copy of C in global memory (L1 / L2) instead of the LDS tile
-                // (would free 22.5 KB of LDS), requested two chunks of four k-steps ahead
+                // b = X~ C on v_mfma_f64_4x4x4 (round 5).  One instruction = four independent 4 x 4 x 4 blocks; block = (kb, sb):
+                // two groups of four DIMENSIONS x two groups of four SAMPLES, so one MFMA covers 8 samples x 4 columns x 8
+                // dimensions.  A = C^T from the operand-ordered copy PassArgs::cpb (one 256-byte block per step and column
+                // group, L1 / L2), B = x~^T from the LDS tile (lane 16 k + 8 kb + 4 sb + j: sample 8 g + 4 sb + j, dimension
+                // 32 s + 16 kb + 4 t + k -- the 16 kb keeps the two dimension groups 16 doubles apart: conflict-free with the
+                // 258-double row stride).  Per wave and tile 96 MFMAs of 17 cycles where the 16 x 16 x 4 form took 32 of
+                // 105-142 (profiles/r04/mfma_peak.txt), the same 32 LDS reads, 48 instead of 32 loads of C, and the two
+                // dimension-group partials summed across lane bit 3 at the end.
+#if !E9_B_EARLYC
+                static_for<LAC>([&](auto q_tag) { cload(q_tag); });
+#endif
+                static_for<LAX>([&](auto q_tag) { xload(q_tag); });
+                static_for<NQ>([&](auto q_tag) {
+                    constexpr int q = decltype(q_tag)::value;
+                    if constexpr (q + LAC < NQ) cload(std::integral_constant<int, q + LAC>{});
+                    if constexpr (q + LAX < NQ) xload(std::integral_constant<int, q + LAX>{});
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < NCGB; ++c)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+                            accb[c][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(cb[q % (LAC + 1)][c], xb[q % (LAX + 1)][g], accb[c][g], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                // the two dimension groups: lane bit 3 (row_ror:8 inside a row of 16 lanes); a + b on both sides, bit-identical.
+                // D[i][j] of block (kb, sb) sits in lane 16 i + 8 kb + 4 sb + j: after the sum lanes with kb = g keep sample group g,
+                // so that lane (l4, l15) holds b[sample 16 rt + l15][column 4 c + l4].
+#pragma unroll
+                for (int c = 0; c < NCGB; ++c) {
+                    const double t0 = accb[c][0] + dpp_f64<0x128, 0xF>(accb[c][0]);
+                    const double t1 = accb[c][1] + dpp_f64<0x128, 0xF>(accb[c][1]);
+                    bsum[c] = kb ? t1 : t0;
+                }
+            }
+#else
+            {
+                // the 16 x 16 x 4 form of rounds 3-4 (kept for A/B runs): B operands from the zero-padded copy of C in global
+                // memory (L1 / L2), requested two chunks of four k-steps ahead
                 constexpr int CH = 4, NCH = STEPS / CH;
                 const double *cg = p.cpad + (DPS * kq + l4) * CS + colb;
                 double axb[2][CH], cbb[3][CH];
@@ -819,9 +867,10 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 }
             }
 #endif
+            E9_FINE(4)   // "P3-load": the b loop
             group(qbA, false);  // digits {3,2}
             group(qbB, false);  // digits {1,0}
-            E9_FINE(0)
+            E9_FINE(0)   // "P2": digit pairs {3,2}, {1,0}
             // the buffer of this parity held the W rows of tile rel - 2: wait until the back role has cut them (long done)
             const unsigned need_dd = rel >= 2 ? 4u * (unsigned)(rel - 1) : 0u;
             if ((int)((unsigned)__builtin_amdgcn_readfirstlane(dd_early) - need_dd) < 0) wait_counter(digdone, need_dd);
@@ -834,7 +883,13 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                         Gcur[(16 * rt2 + 4 * l4 + r) * GS + 16 * wave + l15] = v[rt2][r] * qs;  // (sample-major: the solver's loads pair up into 16-byte reads; entry-major measured 2 % slower)
             }
             // the two K-split partials of b are summed by the solver in a fixed order (p0 + p1)
-#if !E9_B_BACK
+#if E9_B444
+#pragma unroll
+            for (int c = 0; c < NCGB; ++c) {
+                if (kq == 0) Gcur[(16 * rt + l15) * GS + 16 * NTP + 4 * c + l4] = bsum[c];
+                else if (4 * c + l4 < K + 1) B1[(16 * rt + l15) * BS + 4 * c + l4] = bsum[c];
+            }
+#else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (kq == 0) Gcur[(16 * rt + l4 + 4 * r) * GS + 16 * NTP + l15] = accb[r];
@@ -843,7 +898,9 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #endif
         }
         E9_FINE(2)
+#ifndef E9_EXP_NOB1  // (timing experiment, results wrong: what this barrier costs)
         role_barrier(fbar, fbar_target, lane_entry);
+#endif
         // ------------------------------------------------------------ phase beta: solve tile rel | columns of tile rel - 1
         // ONE front wave (rel mod 4) factors the samples of tile rel (lane = sample, lanes 32-63 mirror 0-31), solves for z,
         // leaves factor, z and [wz | w] in the tile's rows and takes the scalars; the other three form the columns of M^-1 of
@@ -875,9 +932,6 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #pragma unroll
                     for (int a = 0; a < K; ++a) z[a] = s2 + (double)a;
 #else
-#if E9_B_BACK
-                    wait_counter(bdone, 4u * (unsigned)(rel + 1));  // the back role has written b of this tile
-#endif
                     fac.load([&](int e) { return g0[e]; }, s2);
 #pragma unroll
                     for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a] + b1[a];
@@ -987,7 +1041,9 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         }
         if (wave == solver) { E9_FINE(6) } else { E9_FINE(8) }  // "factor": the solver's trip; "columns": a column wave's
         // the factor, z and [wz | w] of tile rel and the W rows of tile rel - 1 are final
+#ifndef E9_EXP_NOB2  // (timing experiment, results wrong: what this barrier costs)
         role_barrier(fbar, fbar_target, lane_entry);
+#endif
         E9_FINE(5)
         if (rel > 0 && lane_entry == 0) __hip_atomic_fetch_add(wready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!cur) break;
@@ -995,6 +1051,9 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         // the only reader of the x~ tile; the next tile's rows are requested one per k-step behind the MFMAs
         {
             load_pair(qbA, 6);  // the next tile's first digit pair (the table does not depend on the tile)
+#if E9_QB_EARLY
+            load_pair(qbB, 4);  // ... and its second
+#endif
 #ifndef E9_P4A_AHEAD
 #define E9_P4A_AHEAD 1  // k-steps the LDS operands are requested ahead of their MFMAs (measured: 2 and 3 change nothing -- 95.9 / 95.8 / 95.4 it/s -- and cost registers)
 #endif
@@ -1032,16 +1091,17 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
             }
         }
         E9_FINE(11)
+#ifndef E9_EXP_NOB3  // (timing experiment, results wrong: what this barrier costs)
         role_barrier(fbar, fbar_target, lane_entry);  // the x~ tile is free
+#endif
         E9_FINE(12)
         // ------------------------------------------------------------ P1 of the next tile
         // (its sample masks go into the slot of tile rel - 3: the back role's iterations up to rel - 2 must be over)
         if (rel >= 2) wait_counter(itdone, 4u * (unsigned)(rel - 1));
         stage_tile(tile + 1, lane);
         E9_FINE(13)
+#ifndef E9_EXP_NOB4  // (timing experiment, results wrong: what this barrier costs)
         role_barrier(fbar, fbar_target, lane_entry);
-#if E9_B_BACK
-        if (lane_entry == 0) __hip_atomic_fetch_add(xready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
         E9_FINE(14)
     }

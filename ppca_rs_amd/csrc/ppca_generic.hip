@@ -601,7 +601,10 @@ __global__ __launch_bounds__(256) void gen_colscale_kernel(const double *part, i
         const int64_t rows = (int64_t)(b + 1) * 256 <= n ? 256 : n - (int64_t)b * 256;
         mx = fmax(mx, part[((int64_t)b * 2) * kp + c]);
         sm += bs;
-        mn = fmin(mn, bs / (double)rows);  // the smallest mean magnitude of a 256-row block
+        // the smallest mean magnitude of a 256-row block.  A block whose column sum is exactly 0 (all its rows carry weight 0:
+        // a run of zero weights, sorted data) holds only zeros, which any cut represents exactly: it cannot be damaged by a
+        // coarse scale and must not send the whole chunk to the fp64 engine (advisor, round 4)
+        if (bs > 0.0) mn = fmin(mn, bs / (double)rows);
     }
     rmx[t] = mx;
     rsm[t] = sm;

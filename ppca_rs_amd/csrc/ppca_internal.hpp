@@ -49,10 +49,18 @@ struct PassArgs {
     // EM mode, the guard of the int8 form of the mask-side statistics (launch_em_wguard):
     double *errb;         // [grid][W_GUARD_NCOL]: per workgroup and column of [wP | wz | w], a bound of the rounding the fixed-point
                           // cut added to any sum of that column (written by em8_kernel; nullptr: not collected)
-    const double *cpad;   // zero-padded copy of C, [256][k + 1], written by qprep_kernel (ppca_em9.hip; em8's -DE8_C_GLOBAL)
+    const double *cpad;   // zero-padded copy of C, [256][k + 1], written by qprep_kernel (em8's -DE8_C_GLOBAL experiment)
+    const double *cpb;    // C as the A operands of em9_kernel's b = X~ C on v_mfma_f64_4x4x4, in operand order (CPB_DOUBLES, written
+                          // by qprep_kernel: see cpb_index)
     const int *runflag;   // nullable: the fp64 instantiation of pass_kernel runs iff *runflag != 0 (set by wguard_kernel from the
                           // Gram flags and the W-side check); nullptr: qflag decides as before
 };
+// em9_kernel's b = X~ C (round 5): one v_mfma_f64_4x4x4 = four blocks = (two 4-dim groups kb) x (two 4-sample groups sb); its A
+// operand is C^T: lane 16 k + 8 kb + 4 sb + i holds C[dim][4 c + i] with dim = 128 kq + 32 (q >> 2) + 16 kb + 4 (q & 3) + k for the
+// wave's dimension half kq, step q = 0..15 and column group c -- the same value for sb = 0, 1, so a (kq, q, c) operand is 32
+// doubles, stored contiguously: entry (k, kb, i) at (2 k + kb) 4 + i.  Columns >= K and dimensions >= d are zeros.
+constexpr int CPB_GROUPS = 3;  // column groups of 4 at k = FUSED_MAX_K = 10
+constexpr int CPB_DOUBLES = 2 * 16 * CPB_GROUPS * 32;
 constexpr int W_GUARD_NCOL = 80;  // 16 x ceil((k' + k + 1) / 16) at k = 10
 
 // Number of workgroups the fused pass wants for n rows on a device with n_cu CUs.

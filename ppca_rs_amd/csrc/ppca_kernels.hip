@@ -132,11 +132,17 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     }
     __syncthreads();
     if (j == 0) qflag[t] = bad;
-    if (j == 0 && t == 0) qflag[8] = qflag[9] = 0;  // the pass's run-again flag and the W-side verdict (wguard_kernel)
-    if constexpr (K <= FUSED_MAX_K) {  // tiles this state size does not have: ppca_em_last_guard reads the first four flags whatever
-        // the k of the last pass, and the buffer may have held a larger model's (or the two-kernel pass's) flags
-        if (j == 0 && t == 0)
+    if constexpr (K <= FUSED_MAX_K) {
+        // Slots 8 / 9 are the fused pass's run-again flag and the W-side verdict (wguard_kernel).  ONLY in the fused layout: at
+        // k = 16 this kernel has nine blocks and block 8 files its own tile's verdict in qflag[8] -- an unconditional reset by
+        // block 0 raced with it and could clear the flag of the tile holding column pairs (15, 8..15) (advisor, round 4).
+        // Tiles this state size does not have are cleared too: ppca_em_last_guard reads the first four flags whatever the k of
+        // the last pass, and the buffer may have held a larger model's (or the two-kernel pass's) flags.
+        static_assert(Cfg<K>::NTP <= 8, "slots 8 / 9 must not alias a tile flag");
+        if (j == 0 && t == 0) {
+            qflag[8] = qflag[9] = 0;
             for (int u = (K * (K + 1) / 2 + 15) / 16; u < 8; ++u) qflag[u] = 0;
+        }
     }
     // zero-padded copy of C: ppca_em9.hip (and em8's -DE8_C_GLOBAL experiment) read the B operands of b = X~ C from it.  Only
     // in the layout of fused_qtab_layout (k <= FUSED_MAX_K: the copy sits behind the largest table); the callers with their
@@ -147,6 +153,17 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
         for (int idx = j; idx < FUSED_MAX_D * (K + 1); idx += 256) {
             const int jj = idx / (K + 1), a2 = idx - jj * (K + 1);
             cp[idx] = (jj < d && a2 < K) ? model[MODEL_HDR + (int64_t)jj * K + a2] : 0.0;
+        }
+        // ... and C in the operand order of em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (ppca_internal.hpp, CPB_DOUBLES): one
+        // contiguous 256-byte block per (dimension half, step, column group)
+        double *cb = cp + FUSED_MAX_D * (FUSED_MAX_K + 1);
+        constexpr int NCGB = (K + 3) / 4;
+        for (int idx = j; idx < 2 * 16 * NCGB * 32; idx += 256) {
+            const int e = idx & 31, blk = idx >> 5;
+            const int c = blk % NCGB, q = (blk / NCGB) & 15, kq = blk / (NCGB * 16);
+            const int i = e & 3, kb = (e >> 2) & 1, kk = e >> 3;
+            const int dim = 128 * kq + 32 * (q >> 2) + 16 * kb + 4 * (q & 3) + kk, col = 4 * c + i;
+            cb[idx] = (dim < d && col < K) ? model[MODEL_HDR + (int64_t)dim * K + col] : 0.0;
         }
     }
     const int lane = j & 63, kc = j >> 6;
@@ -1717,12 +1734,13 @@ static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-size_t fused_qtab_bytes() { return qtab_bytes<FUSED_MAX_K>() + (72 + FUSED_MAX_D * (FUSED_MAX_K + 1)) * sizeof(double); }
+size_t fused_qtab_bytes() { return qtab_bytes<FUSED_MAX_K>() + (72 + FUSED_MAX_D * (FUSED_MAX_K + 1) + CPB_DOUBLES) * sizeof(double); }
 void fused_qtab_layout(void *base, PassArgs &a) {  // [64 scales | 8 doubles of guard flags | digit table]
     a.qscale = static_cast<double *>(base);
     a.qflag = reinterpret_cast<int *>(a.qscale + 64);
     a.qtab = reinterpret_cast<signed char *>(a.qscale + 72);
     a.cpad = reinterpret_cast<const double *>(a.qtab + qtab_bytes<FUSED_MAX_K>());  // (behind the largest table)
+    a.cpb = a.cpad + FUSED_MAX_D * (FUSED_MAX_K + 1);
 }
 
 // Gram engine of the fused passes: 0 = int8-sliced MFMA behind the dynamic-range guard, with the fp64-MFMA instantiation

@@ -232,6 +232,7 @@ class _DeviceMixBackend:
         self.cur = [m._device(self.ctx) for m in models]
         self._keep_models = list(models)
         self.n = len(shard)
+        self.rows_used = [0] * len(models)  # rows each component pass gathered in the last step
         self.Ls = [stats_len(self.d, k) for k in self.ks]
         self.offs = np.concatenate([[0], np.cumsum(self.Ls)]).astype(np.int64)
         self.u = torch.empty(max(self.nm * self.n, 1), dtype=torch.float64, device="cuda")
@@ -267,11 +268,13 @@ class _DeviceMixBackend:
         view = self.stats[int(self.offs[c]):int(self.offs[c + 1])]
         if self.n == 0:
             view.zero_()
+            self.rows_used[c] = 0
             return 0.0, view
-        s = C.c_double(0.0)
+        s, used = C.c_double(0.0), C.c_int64(0)
         check(lib().ppca_mix_component_stats(self.ctx.handle, self.shard._h, self.cur[c].h,
                                              C.c_void_p(self.u.data_ptr() + 8 * c * self.n), shift,
-                                             C.c_void_p(view.data_ptr()), C.byref(s), None))
+                                             C.c_void_p(view.data_ptr()), C.byref(s), C.byref(used)))
+        self.rows_used[c] = used.value  # (what ppca_mix_last_rows_used reports for the one-call path)
         return s.value, view
 
     def pack(self, extras: np.ndarray):

@@ -494,6 +494,46 @@ def test_two_kernel_em_pass_chunks_and_guard(P, oracle):
     assert _rel(got, oracle.stats(x, 1e-5, c2, mu, w)) < 1e-4
 
 
+def test_gram_guard_of_the_ninth_tile_at_k16(P, oracle):
+    """k = 16 has NINE packed-column tiles; the ninth (pairs (15, 8..15)) files its verdict in qflag[8], the slot the fused
+    k <= 10 pass uses as its run-again flag.  Round 4's qprep_kernel cleared that slot from block 0 in every instantiation,
+    unordered against block 8's write: a model whose ONLY unsafe tile is the ninth could run on the int8 Gram.  Column 15 of
+    C at 1e3 x the others (entries of equal magnitude), one weak row (so the smallest row norm is small) and a small sigma
+    trip exactly that tile: the guard must report the fp64 engine every time."""
+    from ppca_rs_amd import _lib
+
+    d, k, n = 200, 16, 300
+    rng = np.random.default_rng(16)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 1616)
+    c, mu, s = 0.3 * rng.standard_normal((d, k)), 0.1 * rng.standard_normal(d), 0.03
+    c[:, 15] = 300.0 * np.where(rng.random(d) < 0.5, -1.0, 1.0)
+    c[0] *= 0.1
+    c[0, 15] = 0.0
+    # the guard's own arithmetic (ppca_kernels.hip, qprep_kernel), restated: tile t is unsafe iff neither bound holds
+    eps = lambda cmax: 2.0 ** (np.frexp(cmax)[1] - 63)
+    rmin = (c * c).sum(1).min()
+    unsafe = []
+    for t in range(9):
+        bad = False
+        for cc in range(16 * t, min(16 * t + 16, k * (k + 1) // 2)):
+            a = int((np.sqrt(8 * cc + 1) - 1) // 2)
+            b = cc - a * (a + 1) // 2
+            e = eps(np.abs(c[:, a] * c[:, b]).max())
+            bad |= not (k * d * e <= 1e-8 * s * s or k * k * e <= 2.0 ** -40 * rmin)
+        unsafe.append(bad)
+    assert unsafe == [False] * 8 + [True], unsafe
+    m, ds = P.PPCAModel(s, c, mu), P.Dataset(x)
+    for _ in range(25):  # (the race needed block 0 to finish after block 8)
+        eng = C.c_int32(-1)
+        _lib.check(_lib.lib().ppca_gram_engine(ds._ctx.handle, m._device(ds._ctx).h, C.byref(eng)))
+        assert eng.value == 1
+    L = _lib.lib().ppca_stats_len(d, k)
+    got = np.empty(L)
+    _lib.check(_lib.lib().ppca_stats_raw(ds._ctx.handle, ds._h, m._device(ds._ctx).h, _lib.ptr(got)))
+    # (|G| / sigma^2 ~ 2e10: the oracle's subtractive form keeps about six digits here)
+    assert _rel(got, oracle.stats(x, s, c, mu, None)) < 1e-4
+
+
 def test_reference_usage_patterns():
     """The call patterns of the reference's own examples (examples/*.py: keyword construction, np.matrix and
     transposed inputs, row or column means, positional mask probability, the `ppca_rs.ppca_rs` submodule, pickling,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies the summaries of the final measurement run (tools/gpu_final.sh -> gpurun_out/r2f) into profiles/r02 and
+# Copies the summaries of the final measurement run (tools/leases/gpu_final.sh -> gpurun_out/r2f) into profiles/r02 and
 # writes profiles/r02/traffic.json (HBM bytes per sample of the dominant kernel by the PMC passes at N = 10 M).
 set -e
 R=/root/repo; S=$R/gpurun_out/r2f; D=$R/profiles/r02

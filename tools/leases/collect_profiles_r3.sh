@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies the summaries of the final measurement run (tools/gpu_final_r3.sh -> gpurun_out/r3f) into profiles/r03 and
+# Copies the summaries of the final measurement run (tools/leases/gpu_final_r3.sh -> gpurun_out/r3f) into profiles/r03 and
 # writes profiles/r03/traffic.json (HBM bytes per sample of the dominant kernel by the PMC passes at N = 10 M),
 # traffic_cfg4.json (the generic pipeline's HBM bytes per sample at d = 1024, k = 64) and cliff.md.
 set -e

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies the summaries of the final measurement run (tools/gpu_final_r4.sh -> gpurun_out/r4f) into profiles/r04.
+# Copies the summaries of the final measurement run (tools/leases/gpu_final_r4.sh -> gpurun_out/r4f) into profiles/r04.
 # profiles/r04/traffic.json was written ON THE BOX by tools/make_traffic.py before the bench line that cites it ran.
 set -e
 R=/root/repo; S=$R/gpurun_out/r4f; D=$R/profiles/r04

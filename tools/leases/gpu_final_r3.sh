@@ -1,5 +1,5 @@
 # Final measurements of round 3: everything lands under gpurun_out/r3f and is copied into profiles/r03 by
-# tools/collect_profiles_r3.sh afterwards.
+# tools/leases/collect_profiles_r3.sh afterwards.
 set -x
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3f
 mkdir -p $OUT
@@ -42,6 +42,6 @@ PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_devt.so python tools/time_passes.py 40
 python tools/devbuild16.py --timing > $OUT/devbuild16.log 2>&1
 PPCA_HIP_LIB=$PWD/ppca_rs_amd/libppca_hip_dev16.so python bench.py --n 2000000 --d 200 --k 16 --steps 3 --warmup 1 --no-cpu > $OUT/timing16.json 2> $OUT/timing16.err
 python tools/devbuild.py --name=devllk > /dev/null 2>&1; python tools/devbuild.py -DLLK2_DIAG_RESIDENT --name=devllkres > /dev/null 2>&1
-bash tools/gpu_llk_resident.sh > $OUT/llk2_resident.log 2>&1
+bash tools/leases/gpu_llk_resident.sh > $OUT/llk2_resident.log 2>&1
 python tools/em16_check.py > $OUT/em16_check.log 2>&1
 ls -la $OUT

@@ -1,5 +1,5 @@
 # Final measurements of round 4: everything lands under gpurun_out/r4f and is copied into profiles/r04 by
-# tools/collect_profiles_r4.sh afterwards.  The PMC passes run FIRST and write profiles/r04/traffic.json on the box, so
+# tools/leases/collect_profiles_r4.sh afterwards.  The PMC passes run FIRST and write profiles/r04/traffic.json on the box, so
 # that the bench line that cites it is produced against the file it cites (same commit: tools/commit_stamp.txt).
 set -x
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r4f
