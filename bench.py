@@ -262,6 +262,9 @@ def main() -> None:
                     help="Gram engine of the fused passes: the int8-sliced MFMA behind its dynamic-range guard (auto), or "
                          "the guard's fallback engine, the fp64 MFMA, always (fp64; = PPCA_GRAM_FP64=1)")
     ap.add_argument("--dump-model", default=None, help="rank 0 writes the final model to this .npz (tests)")
+    ap.add_argument("--outliers", type=float, default=0.0,
+                    help="heavy-tailed data: this many rows per million (at fixed global positions) are multiplied by 1e6 -- the regime of "
+                         "the W-side guard: the flagged workgroups' slices are recomputed on the fp64 engine (roofline.fallback)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="a BASELINE.json configuration by number (1: toy 10k x 32 x 4 unmasked; 2: 1M x 256 x 10; 3: the "
                          "headline 10M x 256 x 10 = the default; 4: 2M x 1024 x 64, 50%% block-masked, generic pipeline; "
@@ -355,6 +358,12 @@ def main() -> None:
         c_true = np.random.default_rng(1011).standard_normal((d, k))
         mean_true = np.random.default_rng(1012).standard_normal(d)
         shard = generate(c_true, mean_true, a, b - a, 1013)
+        if args.outliers > 0:
+            # global rows 137 + i * stride (independent of the number of ranks): this shard's are scaled in place
+            stride = max(1, int(round(1e6 / args.outliers)))
+            rows = np.arange(137, n, stride, dtype=np.int64)
+            rows = rows[(rows >= a) & (rows < b)] - a
+            _lib.check(_lib.lib().ppca_dataset_scale_rows(shard._h, rows.ctypes.data_as(C.POINTER(C.c_int64)), len(rows), 1e6))
         c0 = np.random.default_rng(2011).standard_normal(d * k).reshape((k, d)).T.copy()
         start = P.PPCAModel(1.0, c0, np.zeros(d))  # as PPCAModel::init (ppca_model.rs:51-70)
 
@@ -406,6 +415,7 @@ def main() -> None:
     sync()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = ctx.kernel_time(reset=True)
+    fb_mode, fb_wgs, fb_rows, fb_ms = ctx.last_fallback()  # second stage of the guarded EM passes (the last step's verdict; the timed steps' ms)
     ctx.enable_timing(False)
     if world > 1:
         t = torch.tensor([elapsed] + first_iters, dtype=torch.float64, device="cuda")
@@ -521,6 +531,13 @@ def main() -> None:
             "note": "bound = the larger of (algorithmic bytes / HBM peak) and (algorithmic fp64 flops / dense fp64 MFMA peak) "
                     "per sample (SURVEY.md 8d): 0.261 ns vs 0.687 ns at d=256, k=10, so the fp64 pipe; hbm_* = the other one",
         }
+        if not mixture and fused:
+            # second stage of the guarded pass (reduce_wguard_kernel's verdict): what a tripped W-side guard costs -- 0 nothing,
+            # 1 the whole pass again on the fp64 engine, 2 only the flagged workgroups' slices (spread over the grid)
+            roofline["fallback"] = {"mode_last_pass": fb_mode, "workgroups_recomputed": fb_wgs, "rows_recomputed": fb_rows,
+                                    "second_stage_ms_per_step": fb_ms / max(args.steps, 1),
+                                    "note": "HIP events around the fp64 fallback pass + second reduction of every timed step (two launches "
+                                            "that return at once when no guard trips); not part of kernel_avg_ms"}
         sus = sustained_mfma_from_profiles()
         if sus and fp64_bound:
             roofline["sustained_mfma"] = {
@@ -543,7 +560,7 @@ def main() -> None:
             unit = "mixture EM iters/sec"
         else:
             workload = (f"PPCA EM, N={n} samples x d={d}, state_size={k}, {int(100 * args.mask)}% "
-                        f"{'block' if mask_kind else 'iid'} masked, "
+                        f"{'block' if mask_kind else 'iid'} masked, " + (f"{args.outliers:g} outlier rows (x 1e6) per million, " if args.outliers > 0 else "") +
                         f"{world} contiguous row shard(s), one all-reduce of {_lib.lib().ppca_stats_len(d, k)} f64 per step")
             metric = "EM iters/sec (and samples/sec/iter) at N=10M d=256 k=10, 30% masked"
             unit = "EM iters/sec"

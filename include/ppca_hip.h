@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPCA_ABI_VERSION 4
+#define PPCA_ABI_VERSION 5
 
 typedef enum ppca_status {
     PPCA_OK = 0,
@@ -327,6 +327,19 @@ int ppca_gram_engine(ppca_ctx *ctx, const ppca_model *model, int32_t *engine);
  * exponents; dimensions masked in that sample then sum coarsely cut rows): the pass was repeated with fp64 accumulation,
  * as the reference sums (ppca_model.rs:297-306).  Both decided on the device; this call synchronises. */
 int ppca_em_last_guard(ppca_ctx *ctx, int32_t *gram_unsafe, int32_t *stats_unsafe);
+
+/* Bench / test hook: rows[i] of a device-resident dataset multiplied by `factor` in place (masked entries stay masked) -- how
+ * `bench.py --outliers` and the guard tests put outlier samples into data generated on the device.  The dataset must own its
+ * rows (not a slice or weighted view sharing another's).  Synchronises. */
+int ppca_dataset_scale_rows(ppca_dataset *ds, const int64_t *rows, int64_t n_rows, double factor);
+
+/* What the second stage of the most recent EM pass of the fused path did, decided on the device from the guards above
+ * (round 5; stands where the reference's sums are plain f64, ppca_model.rs:297-306): *mode 0 = nothing; 1 = the whole pass again
+ * on the fp64 engine (the model tripped the Gram guard, or too many workgroups were flagged); 2 = only the slices of the
+ * *workgroups workgroups (*rows rows in all) whose fixed-point cut dominated the rounding bound -- an outlier row costs its
+ * workgroup's slice, recomputed by the whole grid, not the pass.  *stage_ms (nullable): HIP-event time of the second stages
+ * (fallback pass + second reduction) since timing was enabled or this was last called (0 without timing).  Synchronises. */
+int ppca_em_last_fallback(ppca_ctx *ctx, int32_t *mode, int32_t *workgroups, int64_t *rows, double *stage_ms);
 
 /* One v_mfma_f64_16x16x4_f64 on host-supplied A (16 x 4) and B (4 x 16), result
  * (16 x 16) written through the C/D lane map the kernels assume (unit test). */

@@ -122,6 +122,8 @@ SIGNATURES = {
     "ppca_ctx_set_grid_limit": (C.c_int, [C.c_void_p, C.c_int32]),
     "ppca_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "ppca_em_last_guard": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
+    "ppca_dataset_scale_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_double]),
+    "ppca_em_last_fallback": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, C.POINTER(C.c_int64), c_double_p]),
     "ppca_gram_engine": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p]),
     "ppca_debug_mfma_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppca_debug_mfma_i8_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -227,6 +229,13 @@ class Context:
         g, w = C.c_int32(0), C.c_int32(0)
         check(lib().ppca_em_last_guard(self.handle, C.byref(g), C.byref(w)))
         return int(g.value), int(w.value)
+
+    def last_fallback(self):
+        """ppca_em_last_fallback: (mode, workgroups recomputed, rows recomputed, ms of the second stages since the last call) of the
+        most recent fused EM pass on this context: mode 0 nothing, 1 the whole pass on the fp64 engine, 2 the flagged slices only."""
+        m, g, r, ms = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_double(0.0)
+        check(lib().ppca_em_last_fallback(self.handle, C.byref(m), C.byref(g), C.byref(r), C.byref(ms)))
+        return int(m.value), int(g.value), int(r.value), float(ms.value)
 
     def enable_timing(self, on: bool) -> None:
         check(lib().ppca_ctx_enable_timing(self.handle, int(on)))

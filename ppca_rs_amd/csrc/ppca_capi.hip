@@ -361,10 +361,11 @@ extern "C" int ppca_ctx_destroy(ppca_ctx *ctx) {
     if (!ctx) return PPCA_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &ev : ctx->events) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
+    for (auto *evs : {&ctx->events, &ctx->events2})
+        for (auto &ev : *evs) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     for (void *q : ctx->pin)
         if (q) (void)hipHostFree(q);
@@ -651,7 +652,29 @@ extern "C" int ppca_dataset_empty_dimensions(ppca_dataset *ds, int32_t *flags) {
     return PPCA_OK;
 }
 
+extern "C" int ppca_dataset_scale_rows(ppca_dataset *ds, const int64_t *rows, int64_t n_rows, double factor) {
+    if (!ds || (n_rows > 0 && !rows) || n_rows < 0) return fail(PPCA_ERR_INVALID, "bad arguments");
+    for (int64_t i = 0; i < n_rows; ++i)
+        if (rows[i] < 0 || rows[i] >= ds->n) return fail(PPCA_ERR_INVALID, "row %lld is outside the dataset", (long long)rows[i]);
+    if (!ds->xbuf || ds->X != static_cast<const double *>(ds->xbuf->p)) return fail(PPCA_ERR_INVALID, "the dataset does not own its rows (a slice or a weighted view)");
+    ppca_ctx *ctx = ds->ctx;
+    USE_CTX(ctx);
+    if (n_rows == 0) return PPCA_OK;
+    BufRef r;
+    if (int rc = dev_alloc(sizeof(int64_t) * (size_t)n_rows, &r)) return rc;
+    HIP_TRY(hipMemcpyAsync(r->p, rows, sizeof(int64_t) * (size_t)n_rows, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_scale_rows(static_cast<double *>(ds->xbuf->p), ds->d, ds->d, static_cast<const int64_t *>(r->p), n_rows, factor, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PPCA_OK;
+}
+
 // ------------------------------------------------------------------ model
+namespace ppca_host {
+void touch(ppca_model *m) {
+    static std::atomic<uint64_t> stamp{0};
+    m->stamp = ++stamp;
+}
+}  // namespace ppca_host
 extern "C" int ppca_model_alloc(ppca_ctx *ctx, int32_t d, int32_t k, ppca_model **out) {
     if (!ctx || !out || d < 1 || k < 0) return fail(PPCA_ERR_INVALID, "bad model shape");
     USE_CTX(ctx);
@@ -663,6 +686,7 @@ extern "C" int ppca_model_alloc(ppca_ctx *ctx, int32_t d, int32_t k, ppca_model 
     if (int rc = dev_alloc(sizeof(double) * (size_t)model_len(d, m->k), &m->buf)) return rc;
     if (m->zero_state)  // (the zero column; a finalisation into this model keeps it at zero: cross = 0)
         HIP_TRY(hipMemsetAsync(m->buf->p, 0, sizeof(double) * (size_t)model_len(d, m->k), ctx->stream));
+    touch(m.get());
     *out = m.release();
     return PPCA_OK;
 }
@@ -680,6 +704,7 @@ extern "C" int ppca_model_create(ppca_ctx *ctx, int32_t d, int32_t k, double sig
     h[3] = 0.0;
     if (k > 0) std::memcpy(h.data() + MODEL_HDR, transform, sizeof(double) * (size_t)d * k);
     std::memcpy(h.data() + MODEL_HDR + (size_t)d * ki, mean, sizeof(double) * d);
+    touch(m);
     hipError_t e = hipMemcpyAsync(m->p(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -723,6 +748,31 @@ static int check_pair(const ppca_dataset *ds, const ppca_model *model) {
     return check_path(model->d, model->k);
 }
 
+// Points a fused pass at the context's slice table and tells it whether the table is already this model's (written by the
+// previous pass of the same model content, or by finalize_qprep_kernel at the end of the EM step that produced it); the pass
+// about to be enqueued makes it this model's either way.
+static int qtab_layout(ppca_ctx *ctx, PassArgs &a) {
+    if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
+    fused_qtab_layout(ctx->qtab->p, a);
+    if (ctx->qtab_base != ctx->qtab->p) {  // a new block: the guard words start at zero (the ticket counter of reduce_wguard_kernel)
+        HIP_TRY(hipMemsetAsync(a.qflag, 0, sizeof(int) * 16, ctx->stream));
+        ctx->qtab_base = ctx->qtab->p;
+        ctx->qtab_model = nullptr;
+    }
+    return PPCA_OK;
+}
+static int qtab_bind(ppca_ctx *ctx, const ppca_model *model, PassArgs &a) {
+    if (int rc = qtab_layout(ctx, a)) return rc;
+    static const bool cache = [] {
+        const char *e = getenv("PPCA_QPREP_CACHE");  // 0: every pass builds its table (rounds 1-4)
+        return !(e && atoi(e) == 0);
+    }();
+    a.skip_qprep = cache && ctx->qtab_model == model->buf->p && ctx->qtab_stamp == model->stamp;
+    ctx->qtab_model = model->buf->p;
+    ctx->qtab_stamp = model->stamp;
+    return PPCA_OK;
+}
+
 // rows / wsel / nsel: gathered pass over nsel rows of the dataset (fused path only): sample i is row rows[i] with
 // weight wsel[i]; rows == nullptr: the whole dataset with its own weights.
 static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, double *stats_dev, const int *rows,
@@ -754,7 +804,8 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
         return PPCA_OK;
     }
     const int grid = fused_grid(n, ctx->n_cu);
-    if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)grid * L.len)) return rc;
+    // partials of the int8 kernel, then those of the fp64 fallback (launch_em_fallback)
+    if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)grid * L.len * 2)) return rc;
     PassArgs a{};
     a.X = ds->X;
     a.ldx = ds->d;
@@ -766,17 +817,27 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
     a.model = model->p();
     a.part = static_cast<double *>(ctx->part->p);
     a.no_llk = ctx->skip_llk;
-    if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
-    fused_qtab_layout(ctx->qtab->p, a);
-    if (int rc = ensure(ctx->errb, ctx->errb_cap, sizeof(double) * (size_t)grid * W_GUARD_NCOL)) return rc;
+    if (int rc = qtab_bind(ctx, model, a)) return rc;
+    // the workgroups' rounding bounds, their column sums, then two int arrays: flagged workgroups as flags and as a list
+    if (int rc = ensure(ctx->errb, ctx->errb_cap, sizeof(double) * ((size_t)grid + 1) * W_GUARD_NCOL + sizeof(int) * 2 * (size_t)grid)) return rc;
     a.errb = static_cast<double *>(ctx->errb->p);
+    GuardArgs g{};
+    g.errb = a.errb;
+    g.es = a.errb + (size_t)grid * W_GUARD_NCOL;
+    g.qflag = a.qflag;
+    g.wgflag = reinterpret_cast<int *>(g.es + W_GUARD_NCOL);
+    g.who = g.wgflag + grid;
+    g.n = a.n;
+    g.n_dev = a.n_dev;
+    g.d = a.d;
+    g.grid = grid;
 #ifdef PPCA_PHASE_TIMING
     BufRef dbg;  // [grid][16] phase sums of one thread per role, then [grid][8 waves][16] per-wave sums (em8_kernel)
     if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 144, &dbg)) return rc;
     HIP_TRY(hipMemsetAsync(dbg->p, 0, sizeof(double) * (size_t)grid * 144, ctx->stream));
     a.dbg = static_cast<double *>(dbg->p);
 #endif
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, f0 = nullptr, f1 = nullptr;
     if (ctx->timing) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
@@ -787,14 +848,21 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
         HIP_TRY(hipEventRecord(e1, ctx->stream));
         ctx->events.emplace_back(e0, e1);
     }
-    HIP_TRY(launch_reduce_partials(a.part, grid, L.len, stats_dev, ctx->stream));
-    {
-        // second stage: the device decides whether the pass is repeated on the fp64 engine (the model tripped the Gram guard,
-        // or the reduced statistics are not large against the rounding of the int8 form of the mask-side contraction);
-        // three launches that return at once otherwise
-        const int *runflag = nullptr;
-        HIP_TRY(launch_em_wguard(model->k, grid, a, stats_dev, ctx->stream, &runflag));
-        if (runflag) HIP_TRY(launch_reduce_partials(a.part, grid, L.len, stats_dev, ctx->stream, 0, runflag));
+    // Reduction + verdict in one launch, then the second stage behind the verdict: nothing (two launches that return at once),
+    // the slices of the flagged workgroups on the fp64 engine, or the whole pass again (ppca_kernels.hip, reduce_wguard_kernel)
+    bool guarded = false;
+    HIP_TRY(launch_reduce_wguard(model->k, a.part, L.len, stats_dev, g, ctx->stream, &guarded));
+    if (guarded) {
+        if (ctx->timing) {  // (its own event pair: a pass whose guard trips spends its time here)
+            HIP_TRY(hipEventCreate(&f0));
+            HIP_TRY(hipEventCreate(&f1));
+            HIP_TRY(hipEventRecord(f0, ctx->stream));
+        }
+        HIP_TRY(launch_em_fallback(model->k, grid, a, g, a.part, a.part + (size_t)grid * L.len, L.len, stats_dev, ctx->stream));
+        if (ctx->timing) {
+            HIP_TRY(hipEventRecord(f1, ctx->stream));
+            ctx->events2.emplace_back(f0, f1);
+        }
     }
 #ifdef PPCA_PHASE_TIMING
     {
@@ -949,8 +1017,10 @@ extern "C" int ppca_em_finalize_host(int32_t d, int32_t k, double sigma, const d
     return PPCA_OK;
 }
 
-extern "C" int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const double *stats_dev,
-                                const ppca_prior *prior, ppca_model *out) {
+// with_table: the plain EM steps (ppca_em_step, _sharded, _group) -- the finalisation also builds the slice table, guard flags and
+// padded C of the NEW model in the same launch (fused path), so that the next pass of `out` on this context starts at once
+static int em_finalize_impl(ppca_ctx *ctx, const ppca_model *model_in, const double *stats_dev, const ppca_prior *prior, ppca_model *out,
+                            bool with_table) {
     if (!ctx || !model_in || !stats_dev || !out) return fail(PPCA_ERR_INVALID, "null argument");
     if (out == model_in || out->buf == model_in->buf) return fail(PPCA_ERR_INVALID, "out may not alias model_in");
     if (out->d != model_in->d || out->k != model_in->k || out->zero_state != model_in->zero_state)
@@ -961,14 +1031,28 @@ extern "C" int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const
     const int d = model_in->d, k = model_in->k;
     const double tau = prior ? prior->transformation_precision : 0.0;
     const int has_ig = prior ? prior->has_isotropic_noise_prior : 0;
+    touch(out);  // (the mean prior below changes the mean only: the slice table depends on the transform and sigma^2)
     if (ppca_path_kind(d, k) == 0) {
         HIP_TRY(generic_finalize(k, d, stats_dev, model_in->p(), out->p(), tau, has_ig,
                                  has_ig ? prior->isotropic_noise_alpha : 0.0, has_ig ? prior->isotropic_noise_beta : 0.0,
                                  ctx->n_cu, ctx->stream));
     } else {
-        HIP_TRY(launch_finalize(k, d, stats_dev, model_in->p(), out->p(), tau, has_ig,
-                                has_ig ? prior->isotropic_noise_alpha : 0.0, has_ig ? prior->isotropic_noise_beta : 0.0,
-                                ctx->stream));
+        static const bool fuse = [] {
+            const char *e = getenv("PPCA_QPREP_CACHE");  // 0: every pass builds its table (rounds 1-4)
+            return !(e && atoi(e) == 0);
+        }();
+        if (with_table && fuse) {
+            PassArgs tab{};
+            if (int rc = qtab_layout(ctx, tab)) return rc;
+            HIP_TRY(launch_finalize_qprep(k, d, stats_dev, model_in->p(), out->p(), tau, has_ig, has_ig ? prior->isotropic_noise_alpha : 0.0,
+                                          has_ig ? prior->isotropic_noise_beta : 0.0, tab, ctx->stream));
+            ctx->qtab_model = out->buf->p;
+            ctx->qtab_stamp = out->stamp;
+        } else {
+            HIP_TRY(launch_finalize(k, d, stats_dev, model_in->p(), out->p(), tau, has_ig,
+                                    has_ig ? prior->isotropic_noise_alpha : 0.0, has_ig ? prior->isotropic_noise_beta : 0.0,
+                                    ctx->stream));
+        }
     }
     if (prior && prior->has_mean_prior) {
         // rare branch (d x d solve, prior.rs:97-110): host round trip
@@ -988,6 +1072,17 @@ extern "C" int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const
     return PPCA_OK;
 }
 
+extern "C" int ppca_em_finalize(ppca_ctx *ctx, const ppca_model *model_in, const double *stats_dev,
+                                const ppca_prior *prior, ppca_model *out) {
+    // (with the table: a host that composes the step itself -- accumulate, its own all-reduce, finalize -- runs `out` next)
+    return em_finalize_impl(ctx, model_in, stats_dev, prior, out, true);
+}
+namespace ppca_host {
+int em_finalize_with_table(ppca_ctx *ctx, const ppca_model *model_in, const double *stats_dev, const ppca_prior *prior, ppca_model *out) {
+    return em_finalize_impl(ctx, model_in, stats_dev, prior, out, true);
+}
+}  // namespace ppca_host
+
 extern "C" int ppca_em_step(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model_in, const ppca_prior *prior,
                             ppca_model *out, double *llk_in) {
     if (!ctx || !out) return fail(PPCA_ERR_INVALID, "null argument");
@@ -998,7 +1093,7 @@ extern "C" int ppca_em_step(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *m
     if (int rc = ensure(ctx->stats, ctx->stats_cap, sizeof(double) * (size_t)L.len)) return rc;
     double *stats = static_cast<double *>(ctx->stats->p);
     if (int rc = ppca_em_accumulate(ctx, ds, model_in, stats)) return rc;
-    if (int rc = ppca_em_finalize(ctx, model_in, stats, prior, out)) return rc;
+    if (int rc = em_finalize_impl(ctx, model_in, stats, prior, out, true)) return rc;
     ctx->stats_llk_at = L.scalars + SC_LLK;
     if (llk_in) {
         HIP_TRY(hipMemcpyAsync(llk_in, stats + L.scalars + SC_LLK, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1064,8 +1159,7 @@ static int run_post(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, do
         a.covs = covs_dev;
         a.recon = recon_dev;
         a.recon_mode = recon_mode;
-        if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
-        fused_qtab_layout(ctx->qtab->p, a);
+        if (int rc = qtab_bind(ctx, model, a)) return rc;
 #ifdef PPCA_PHASE_TIMING
         BufRef dbg;
         if (int rc = dev_alloc(sizeof(double) * (size_t)grid * 16, &dbg)) return rc;
@@ -1357,9 +1451,10 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
         if (any_fused && n < (int64_t)1 << 31) {
             if (int rc = ensure(ctx->mix[5], ctx->mix_cap[5], sizeof(int) * (size_t)n)) return rc;
             if (int rc = ensure(ctx->mix[6], ctx->mix_cap[6], sizeof(int) * ((size_t)select_blocks(n) + 1))) return rc;
-            if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)grid * max_len)) return rc;
+            // (what em_accumulate_impl will ask for: the partials of both stages, the bounds + workgroup flags)
+            if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)grid * max_len * 2)) return rc;
             if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
-            if (int rc = ensure(ctx->errb, ctx->errb_cap, sizeof(double) * (size_t)grid * W_GUARD_NCOL)) return rc;
+            if (int rc = ensure(ctx->errb, ctx->errb_cap, sizeof(double) * ((size_t)grid + 1) * W_GUARD_NCOL + sizeof(int) * 2 * (size_t)grid)) return rc;
         }
         if (gws_bytes)
             if (int rc = ensure(ctx->gws, ctx->gws_cap, gws_bytes)) return rc;
@@ -1394,8 +1489,8 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
     if (comm) {
         if (int rc = ppca_comm_allreduce(comm, pack, total, 0)) return rc;
     }
-    for (int c = 0; c < nm; ++c)
-        if (int rc = ppca_em_finalize(ctx, models_in[c], pack + off[c], prior, models_out[c])) return rc;
+    for (int c = 0; c < nm; ++c)  // (plain finalisation: the context has ONE slice table, the next iteration walks K models)
+        if (int rc = em_finalize_impl(ctx, models_in[c], pack + off[c], prior, models_out[c], false)) return rc;
     HIP_TRY(launch_mix_logweights(pack + sums_at, aux, pack + llk_at, nm, aux + 256, ctx->stream));
     double *hs = static_cast<double *>(ctx->hstage);
     HIP_TRY(hipMemcpyAsync(hs, aux + 256, sizeof(double) * (size_t)(nm + 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -1559,8 +1654,36 @@ extern "C" int ppca_em_last_guard(ppca_ctx *ctx, int32_t *gram_unsafe, int32_t *
         HIP_TRY(hipMemcpyAsync(flags, a.qflag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    if (gram_unsafe) *gram_unsafe = (flags[0] | flags[1] | flags[2] | flags[3]) ? 1 : 0;
-    if (stats_unsafe) *stats_unsafe = flags[9];
+    // (the verdicts reduce_wguard_kernel filed for the PASS: the tile flags themselves may already be the next model's --
+    //  finalize_qprep_kernel builds its table at the end of the step)
+    if (gram_unsafe) *gram_unsafe = flags[QF_GVERDICT];
+    if (stats_unsafe) *stats_unsafe = flags[QF_WVERDICT];
+    return PPCA_OK;
+}
+
+extern "C" int ppca_em_last_fallback(ppca_ctx *ctx, int32_t *mode, int32_t *workgroups, int64_t *rows, double *stage_ms) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "null context");
+    USE_CTX(ctx);
+    int flags[16] = {0};
+    if (ctx->qtab) {
+        PassArgs a{};
+        fused_qtab_layout(ctx->qtab->p, a);
+        HIP_TRY(hipMemcpyAsync(flags, a.qflag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (mode) *mode = flags[QF_MODE];
+    if (workgroups) *workgroups = flags[QF_NFLAGGED];
+    if (rows) *rows = flags[QF_NROWS2];
+    double tot = 0.0;
+    for (auto &ev : ctx->events2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    ctx->events2.clear();
+    if (stage_ms) *stage_ms = tot;
     return PPCA_OK;
 }
 
@@ -1603,11 +1726,10 @@ extern "C" int ppca_gram_engine(ppca_ctx *ctx, const ppca_model *model, int32_t 
         *engine = flag ? 1 : 0;
         return PPCA_OK;
     }
-    if (int rc = ensure(ctx->qtab, ctx->qtab_cap, fused_qtab_bytes())) return rc;
     PassArgs a{};
     a.model = model->p();
     a.d = model->d;
-    fused_qtab_layout(ctx->qtab->p, a);
+    if (int rc = qtab_bind(ctx, model, a)) return rc;  // (launch_gram_guard always builds the table: it is this model's afterwards)
     int forced = -1;
     HIP_TRY(launch_gram_guard(model->k, a, ctx->stream, &forced));
     if (forced >= 0) {

@@ -220,7 +220,7 @@ extern "C" int ppca_em_step_sharded(ppca_comm *comm, ppca_dataset *shard, const 
     double *stats = static_cast<double *>(ctx->stats->p);
     if (int rc = ppca_em_accumulate(ctx, shard, model_in, stats)) return rc;  // an empty shard contributes zeros
     if (int rc = ppca_comm_allreduce(comm, stats, L.len, 0)) return rc;
-    if (int rc = ppca_em_finalize(ctx, model_in, stats, prior, out)) return rc;
+    if (int rc = ppca_host::em_finalize_with_table(ctx, model_in, stats, prior, out)) return rc;
     ctx->stats_llk_at = L.scalars + SC_LLK;
     if (llk_in) {
         HIP_TRY(hipMemcpyAsync(llk_in, stats + L.scalars + SC_LLK, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -278,7 +278,7 @@ extern "C" int ppca_em_step_group(ppca_comm *const *comms, int32_t n, ppca_datas
     RCCL_TRY(r, r->GroupEnd());
     for (int i = 0; i < n; ++i) {
         ppca_ctx *ctx = comms[i]->ctx;
-        if (int rc = ppca_em_finalize(ctx, models_in[i], static_cast<double *>(ctx->stats->p), prior, models_out[i])) return rc;
+        if (int rc = ppca_host::em_finalize_with_table(ctx, models_in[i], static_cast<double *>(ctx->stats->p), prior, models_out[i])) return rc;
         ctx->stats_llk_at = L.scalars + SC_LLK;
     }
     if (llk_in) {

@@ -49,6 +49,9 @@ constexpr int E9_FLUSH_GROUPS = 100;
                    // E9_EXP_CLDS, results wrong) the loop takes 2.22 k and the launch 104.8 it/s -- but LDS has 1.7 KB free where 20 KB are
                    // needed, and what can be reclaimed (66-column digit planes 6.3, mean 2, row stride 2, second b partial 2.8) stops at 15.
 #endif
+#if E9_B444 && !defined(PPCA_WITH_CPB)
+#error "E9_B444=1 reads PassArgs::cpb: build ppca_kernels.hip with -DPPCA_WITH_CPB as well (tools/devbuild.py passes -D flags to both)"
+#endif
 #ifndef E9_B_EARLYC
 #define E9_B_EARLYC 1  // the first steps of C operands requested before the Gram's digit pairs (their L2 latency under the integer MFMAs)
 #endif

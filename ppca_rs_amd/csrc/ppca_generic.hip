@@ -695,6 +695,15 @@ struct I8GemmArgs {
 // BUF: operands through buffer descriptors (per-thread piece offsets computed once, the K position a scalar offset:
 // no vector address arithmetic in the K loop -- the pointer form spent 2.7 vector instructions per MFMA on 64-bit
 // addresses and bounds, SQ_INSTS_VALU 338 M against SQ_INSTS_MFMA 91 M per launch); needs both operands < 2 GiB.
+#ifndef I8_PIPE
+#define I8_PIPE 2  // 2: the K loop as a three-stage pipeline (round 5): three LDS buffers, the staging of step i + 2 and the global request
+                   // of step i + 3 between the MFMA batches of step i, the first fragments of step i + 1 requested before the
+                   // step's barrier; 1: the pipeline inside one step only (two buffers); 0: rounds 2-4 (all fragment reads, all MFMAs,
+                   // staging, request, barrier)
+#endif
+#ifndef I8_RAW_BARRIER
+#define I8_RAW_BARRIER 0
+#endif
 #ifndef I8_STAGES
 #define I8_STAGES 1  // measured at config 4 (round 2): 1 -> 254.0, 2 -> 253.4, 3 -> 253.2, 4 -> 262.4 ms (spills); the registers go to the fragments
 #endif
@@ -712,8 +721,9 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
     // 0.9-1.1e9 against SQ_ACTIVE_INST_LDS 0.4-0.6e9 per launch (round 2, gpurun_out/pmcgen).
     extern __shared__ __attribute__((aligned(16))) unsigned char i8sm[];
     constexpr int AROWS = TM, BROWS = GQS * 32;
-    unsigned char *As = i8sm;                              // [2][4][TM][16]
-    unsigned char *Bs = i8sm + 2 * 4 * AROWS * 16;         // [2][4][GQS * 32][16]
+    constexpr int NBUF = (I8_PIPE == 2 && BUF) ? 3 : 2;
+    unsigned char *As = i8sm;                              // [NBUF][4][TM][16]
+    unsigned char *Bs = i8sm + NBUF * 4 * AROWS * 16;      // [NBUF][4][GQS * 32][16]
     auto slot = [](int rows, int buf, int row, int q) {    // byte offset of (row, piece q) in buffer buf
         const int g = (q & 1) * 2 + (q >> 1) * 12;         // 0, 2, 12, 14
         return ((buf * 4 + q) * rows + (row ^ g)) * 16;
@@ -804,7 +814,38 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
             *reinterpret_cast<gi4_t *>(Bs + slot(BROWS, buf, piece / PR, piece % PR)) = rb[st][u];
         }
     };
-    auto compute = [&](int buf) {
+#if I8_PIPE
+    // (round 5) The K-step as a software pipeline inside the wave: the B fragments of slice pair p + 1 are requested before the
+    // eight MFMAs of pair p issue, so that from the second pair on the LDS reads run under the matrix pipe; the next step's
+    // staging (LDS stores of the rows fetched one step ago: `mid0`) goes behind the first pair's MFMAs and the global request of
+    // the step after it (`mid1`) behind the second.  Rounds 2-4 requested all twelve fragments, waited, issued the 32 MFMAs,
+    // staged, fetched, and met at the barrier: per step 1 130 cycles of MFMAs + 1 000 of LDS traffic took 3 400 --
+    // eight waves reading together, then multiplying together, then staging together.
+    auto compute = [&](int buf, auto &&mid0, auto &&mid1) {
+        gi4_t fa[4], fb[GQS];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const gi4_t *>(As + slot(AROWS, buf, 64 * wm + 16 * a + l15, l4));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fb[s] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, buf, s * 32 + 16 * wn + l15, l4));
+        static_for_g<GQS / 2>([&](auto p_tag) {
+            constexpr int p = decltype(p_tag)::value;
+            if constexpr (2 * p + 2 < GQS) {
+#pragma unroll
+                for (int s = 2 * p + 2; s < 2 * p + 4; ++s)
+                    fb[s] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, buf, s * 32 + 16 * wn + l15, l4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 2 * p; s < 2 * p + 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (p == 0) mid0();
+            if constexpr (p == 1) mid1();
+        });
+    };
+#else
+    auto compute = [&](int buf, auto &&mid0, auto &&mid1) {
         // every fragment of the K-step is requested before the first MFMA (12 reads in flight: the LDS latency is paid
         // once per step, not once per slice pair as hipcc schedules the interleaved form)
         gi4_t fa[4], fb[GQS];
@@ -818,7 +859,73 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        mid0();
+        mid1();
     };
+#endif
+#if I8_PIPE == 2
+    if constexpr (BUF) {
+        // Step i contracts buffer i % 3 while it stages step i + 2 into buffer (i + 2) % 3 (last read in step i - 1: the barrier
+        // that ended it), requests step i + 3 from global memory and, after its last MFMAs have issued, already requests the first
+        // fragments of step i + 1 from buffer (i + 1) % 3 (staged during step i - 1, visible since the same barrier): the only
+        // LDS latency a step still waits for is hidden behind the previous step's MFMAs and the barrier.  Reads past K return
+        // zeros (buffer descriptors), so the tail needs no special case.
+        const int nsteps = (int)((kend - kbeg) / KB);
+        gi4_t fa[4], fb[GQS];
+        auto first_frags = [&](auto b_tag) {
+            constexpr int b = decltype(b_tag)::value;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const gi4_t *>(As + slot(AROWS, b, 64 * wm + 16 * a + l15, l4));
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) fb[s2] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, b, s2 * 32 + 16 * wn + l15, l4));
+        };
+        auto step = [&](auto b_tag, int i) {
+            constexpr int b = decltype(b_tag)::value;
+            static_for_g<GQS / 2>([&](auto p_tag) {
+                constexpr int p = decltype(p_tag)::value;
+                if constexpr (2 * p + 2 < GQS) {
+#pragma unroll
+                    for (int s2 = 2 * p + 2; s2 < 2 * p + 4; ++s2)
+                        fb[s2] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, b, s2 * 32 + 16 * wn + l15, l4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 2 * p; s2 < 2 * p + 2; ++s2)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a][s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s2], acc[a][s2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (p == 0) stash((b + 2) % 3, 0);                          // step i + 2
+                if constexpr (p == 1) fetch(kbeg + (int64_t)(i + 3) * KB, 0);         // step i + 3
+            });
+            first_frags(std::integral_constant<int, (b + 1) % 3>{});                  // step i + 1
+            __builtin_amdgcn_sched_barrier(0);
+#if I8_RAW_BARRIER
+            // s_barrier WITHOUT the s_waitcnt lgkmcnt(0) that __syncthreads() puts in front of it: this wave's only LDS stores of
+            // the step (the staging behind the first MFMA batch) were followed by fragment reads whose data the later batches have
+            // already consumed -- a wave's LDS operations complete in order, so the stores are done; what is still in flight are
+            // the six reads of the NEXT step's first fragments, from a buffer nobody writes before the barrier after this one.
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#else
+            __syncthreads();
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fetch(kbeg, 0);
+        stash(0, 0);
+        fetch(kbeg + KB, 0);
+        stash(1, 0);
+        fetch(kbeg + 2 * (int64_t)KB, 0);
+        __syncthreads();
+        first_frags(std::integral_constant<int, 0>{});
+        for (int i = 0; i < nsteps; i += 3) {
+            step(std::integral_constant<int, 0>{}, i);
+            if (i + 1 < nsteps) step(std::integral_constant<int, 1>{}, i + 1);
+            if (i + 2 < nsteps) step(std::integral_constant<int, 2>{}, i + 2);
+        }
+    } else
+#endif
     if constexpr (BUF) {
         // ST K-steps travel in registers while one is contracted out of LDS: a step is requested ST iterations (ST x
         // ~1 k cycles of MFMAs per SIMD) before it is staged.  (The MFMA pipe is 30 % busy in this kernel by
@@ -834,9 +941,8 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
             for (int j = 0; j < ST; ++j) {
                 if (i + j < nsteps) {  // (uniform)
                     const int buf = (i + j) & 1;
-                    compute(buf);
-                    stash(buf ^ 1, (j + 1) % ST);                                       // step i + j + 1
-                    fetch(kbeg + (int64_t)(i + j + 1 + ST) * KB, (j + 1) % ST);        // step i + j + 1 + ST
+                    compute(buf, [&] { stash(buf ^ 1, (j + 1) % ST); },                                       // step i + j + 1
+                            [&] { fetch(kbeg + (int64_t)(i + j + 1 + ST) * KB, (j + 1) % ST); });              // step i + j + 1 + ST
                     __syncthreads();
                 }
             }
@@ -849,7 +955,7 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
         for (int64_t k0 = kbeg; k0 < kend; k0 += KB) {
             const bool more = k0 + KB < kend;
             if (more) fetch(k0 + KB, 0);
-            compute(buf);
+            compute(buf, [] {}, [] {});
             if (more) stash(buf ^ 1, 0);
             __syncthreads();
             buf ^= 1;
@@ -2111,7 +2217,7 @@ __global__ void add_partial_kernel(double *out, int64_t ldo, const double *part,
 
 template <int TM, bool BUF>
 static hipError_t launch_i8gemm_t(const I8GemmArgs &g, dim3 grid, hipStream_t s) {
-    const size_t lds = 2 * (TM + GQS * 32) * 64;
+    const size_t lds = ((I8_PIPE == 2 && BUF) ? 3 : 2) * (size_t)(TM + GQS * 32) * 64;
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;

@@ -69,8 +69,14 @@ struct ppca_ctx {
     BufRef work;  // 2048 doubles for reductions
     BufRef qtab;  // int8 Gram slice table + scales + guard flags of the model being processed
     size_t qtab_cap = 0;
-    BufRef errb;  // [grid][W_GUARD_NCOL] rounding bounds of the int8 mask-side statistics (wguard_kernel)
+    BufRef errb;  // [grid + 1][W_GUARD_NCOL] rounding bounds of the int8 mask-side statistics and their column sums, then 2 x [grid]
+                  // ints: the workgroups whose slices the fp64 fallback recomputes, as flags and as a list (reduce_wguard_kernel)
     size_t errb_cap = 0;
+    // which model the slice table / guard flags / padded C behind qtab belong to (base pointer of the table, device buffer and
+    // write stamp of the model): a pass of that model launches no qprep_kernel (PassArgs::skip_qprep)
+    const void *qtab_base = nullptr, *qtab_model = nullptr;
+    uint64_t qtab_stamp = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events2;  // (timing) the second stage of the guarded EM passes: fallback + reduction
     BufRef gws;   // workspace of the generic split pipeline
     size_t gws_cap = 0;
     // mixture scratch, kept across iterations (hipMalloc / hipFree of hundreds of MB per component cost more than
@@ -112,6 +118,8 @@ struct ppca_model {
     int k_user() const { return zero_state ? 0 : k; }
     BufRef buf;
     double *p() const { return static_cast<double *>(buf->p); }
+    uint64_t stamp = 0;  // changes whenever something is enqueued that writes the buffer (ppca_host::touch): with the buffer's address it
+                         // names the model's CONTENT for the contexts' cached slice tables
 };
 
 ppca_ctx *ppca_comm_context(ppca_comm *comm);  // ppca_comm.hip (internal)
@@ -124,6 +132,9 @@ BufRef dev_borrow(const void *p);
 int ensure(BufRef &b, size_t &cap, size_t bytes);
 int use_device(const ppca_ctx *ctx);
 int ensure_hstage(ppca_ctx *ctx, size_t bytes);
+void touch(ppca_model *m);  // the model's buffer is (about to be) written: new stamp
+// ppca_em_finalize that also builds the new model's slice table in the same launch (the plain EM steps), ppca_capi.hip
+int em_finalize_with_table(ppca_ctx *ctx, const ppca_model *model_in, const double *stats_dev, const ppca_prior *prior, ppca_model *out);
 // PPCAMix::iterate_with_prior over the context's rows (comm nullable: one row shard of several), ppca_capi.hip
 int mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppca_model *const *models_in, const double *log_weights_in,
                 int32_t nm, const ppca_prior *prior, ppca_model *const *models_out, double *log_weights_out, double *llk_in);

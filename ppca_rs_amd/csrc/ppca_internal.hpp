@@ -52,13 +52,36 @@ struct PassArgs {
     const double *cpad;   // zero-padded copy of C, [256][k + 1], written by qprep_kernel (em8's -DE8_C_GLOBAL experiment)
     const double *cpb;    // C as the A operands of em9_kernel's b = X~ C on v_mfma_f64_4x4x4, in operand order (CPB_DOUBLES, written
                           // by qprep_kernel: see cpb_index)
-    const int *runflag;   // nullable: the fp64 instantiation of pass_kernel runs iff *runflag != 0 (set by wguard_kernel from the
-                          // Gram flags and the W-side check); nullptr: qflag decides as before
+    const int *runflag;   // nullable: second stage of a guarded EM pass (launch_em_fallback): the fp64 instantiation of pass_kernel
+                          // reads the verdict of reduce_wguard_kernel: 0 = return at once; 1 = the whole pass again; 2 = only the
+                          // slices (runs of tiles, as the guarded launch dealt them) of the flagged workgroups `who`, each slice
+                          // split over gridDim.x / n_flagged workgroups; nullptr: qflag decides as before
+    const int *who;       // [n_flagged] (runflag[QF_NFLAGGED - QF_MODE]) ascending workgroup indices of the guarded launch
+    int skip_qprep;       // the slice table / guard flags / padded C behind qtab are already those of `model` (written by
+                          // finalize_qprep_kernel at the end of the previous EM step): the pass launches no qprep_kernel
 };
-// em9_kernel's b = X~ C (round 5): one v_mfma_f64_4x4x4 = four blocks = (two 4-dim groups kb) x (two 4-sample groups sb); its A
-// operand is C^T: lane 16 k + 8 kb + 4 sb + i holds C[dim][4 c + i] with dim = 128 kq + 32 (q >> 2) + 16 kb + 4 (q & 3) + k for the
-// wave's dimension half kq, step q = 0..15 and column group c -- the same value for sb = 0, 1, so a (kq, q, c) operand is 32
-// doubles, stored contiguously: entry (k, kb, i) at (2 k + kb) 4 + i.  Columns >= K and dimensions >= d are zeros.
+// Guard words behind PassArgs::qflag (ints): [0, 8) the Gram guard's per-tile flags (qprep_kernel); [8] the fallback's mode (see
+// PassArgs::runflag); [9] the verdict of the W-side check; [10] ticket counter of reduce_wguard_kernel's last-block election;
+// [11] workgroups whose slices the fallback recomputes; [12] rows in those slices; [13] the Gram guard's verdict for the pass (the tile
+// flags themselves are overwritten by the NEXT model's when the step's finalisation builds its table).
+constexpr int QF_MODE = 8, QF_WVERDICT = 9, QF_TICKET = 10, QF_NFLAGGED = 11, QF_NROWS2 = 12, QF_GVERDICT = 13;
+// What reduce_wguard_kernel needs beside the partials.
+struct GuardArgs {
+    const double *errb;   // [grid][W_GUARD_NCOL] rounding bounds of the workgroups' cuts; nullptr: no W-side check (kernels that
+                          // do not cut their rows: only the Gram flags decide)
+    double *es;           // [W_GUARD_NCOL] scratch: their column sums (written by the reduction's extra workgroups)
+    int *qflag;           // the guard words above
+    int *wgflag;          // [grid]: 1 = the workgroup's partial is replaced by the fallback's
+    int *who;             // [grid]: the flagged workgroups, ascending (PassArgs::who of the fallback)
+    int64_t n;            // the guarded pass's row count (n_dev nullable: read from the device)
+    const int *n_dev;
+    int d;
+    int grid;             // workgroups of the guarded launch (= partials)
+};
+// em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (round 5 experiment, -DE9_B444=1 -DPPCA_WITH_CPB): one instruction = four blocks = (two
+// 4-dim groups kb) x (two 4-sample groups sb); its A operand is C^T: lane 16 k + 8 kb + 4 sb + i holds C[dim][4 c + i] with
+// dim = 128 kq + 32 (q >> 2) + 16 kb + 4 (q & 3) + k for the wave's dimension half kq, step q = 0..15 and column group c -- the same
+// value for sb = 0, 1, so a (kq, q, c) operand is 32 doubles, stored contiguously: entry (k, kb, i) at (2 k + kb) 4 + i.
 constexpr int CPB_GROUPS = 3;  // column groups of 4 at k = FUSED_MAX_K = 10
 constexpr int CPB_DOUBLES = 2 * 16 * CPB_GROUPS * 32;
 constexpr int W_GUARD_NCOL = 80;  // 16 x ceil((k' + k + 1) / 16) at k = 10
@@ -116,12 +139,25 @@ hipError_t launch_em16(int k, int grid, const Em16Launch &a, hipStream_t s);
 hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s);
 hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s, int accumulate = 0,
                                   const int *run_if = nullptr);  // run_if: device flag; the kernel returns at once when it is 0
-// Second stage of a guarded EM pass, after the partials of launch_pass_em were reduced into `stats`: wguard_kernel decides
-// on the device whether the pass must be repeated on the fp64 engine (the Gram guard's flags, or the statistics' own
-// check: a diagonal entry of S that is not large against the rounding bound of its column), and the fp64 instantiation of
-// the pass runs behind that flag.  *runflag_out: the device flag the caller hands to the second launch_reduce_partials
-// (nullptr when the stage does not apply: an engine pinned by the environment, kernel-tuning builds).
-hipError_t launch_em_wguard(int k, int grid, PassArgs a, const double *stats, hipStream_t s, const int **runflag_out);
+// A guarded EM pass of the fused path after launch_pass_em, in two launches (round 5; rounds 3-4: reduction, wguard_kernel,
+// fp64 pass, second reduction):
+//   launch_reduce_wguard   sums the partials into `stats` (the fixed order of launch_reduce_partials); the LAST workgroup of
+//                          that reduction then decides on the device what the second stage does (GuardArgs, QF_MODE): nothing;
+//                          the whole pass again on the fp64 engine (the model tripped the Gram guard, or too many workgroups are
+//                          flagged); or only the slices of the workgroups whose cut dominates the rounding bound of a column whose
+//                          reduced diagonal entry of S is not large against it -- an outlier row costs its workgroup's slice,
+//                          spread over the whole grid, not the pass.
+//   launch_em_fallback     the fp64 instantiation of the pass behind that mode (returns at once on 0) into `part2`, then
+//                          stats = sum of the un-flagged workgroups' partials + sum of part2 (returns at once on 0).
+// Both return hipSuccess without launching anything when the stage does not apply (an engine pinned by the environment,
+// kernel-tuning builds): *applies_out tells.
+hipError_t launch_reduce_wguard(int k, const double *part, int64_t len, double *stats, const GuardArgs &g, hipStream_t s, bool *applies_out);
+hipError_t launch_em_fallback(int k, int grid, PassArgs a, const GuardArgs &g, const double *part, double *part2, int64_t len, double *stats,
+                              hipStream_t s);
+// finalize_kernel + the slice table / guard flags / padded C of the NEW model in one launch (the plain EM step: the next pass of
+// that model then runs with PassArgs::skip_qprep)
+hipError_t launch_finalize_qprep(int k, int d, const double *stats, const double *model_in, double *model_out, double tau, int has_ig,
+                                 double alpha, double beta, const PassArgs &tab, hipStream_t s);
 hipError_t launch_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
                            int has_ig, double alpha, double beta, hipStream_t s);
 hipError_t launch_synth(const double *c_dev, const double *mean_dev, double *z_work, double *x_out, int64_t row_offset,
@@ -131,6 +167,7 @@ hipError_t launch_column_presence(const double *X, int64_t ldx, int64_t n, int d
 hipError_t launch_fill(double *p, int64_t n, double v, hipStream_t s);
 // dst[i] = finite(src[i]) ? src[i] : NaN (src, dst 16-byte aligned)
 hipError_t launch_canon_copy(const double *src, double *dst, int64_t n, hipStream_t s);
+hipError_t launch_scale_rows(double *X, int64_t ldx, int d, const int64_t *rows_dev, int64_t n_rows, double factor, hipStream_t s);
 // debug: C/D layout probe of v_mfma_f64_16x16x4_f64 (out: 16 x 16 row-major)
 hipError_t launch_mfma_i8_probe(const int *a, const int *b, int *out, hipStream_t s);
 hipError_t launch_mfma_probe(const double *a16x4, const double *b4x16, double *out16x16, hipStream_t s);

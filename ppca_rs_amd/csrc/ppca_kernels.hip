@@ -59,9 +59,9 @@ namespace ppca {
 constexpr double QGUARD_FWD = 1.0e-8;
 constexpr double QGUARD_BWD = 9.094947017729282e-13;  // 2^-40
 
-template <int K>
-__global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, double *qscale, signed char *qtab,
-                                                    int *qflag) {
+// (the body: C(j, a) reads the transform -- from the model buffer, or from the LDS copy finalize_qprep_kernel has just computed)
+template <int K, class CF>
+__device__ __forceinline__ void qprep_body(CF C, double s2m, int d, double *qscale, signed char *qtab, int *qflag) {
     constexpr int KP = Cfg<K>::KP;
     __shared__ unsigned long long cmax[16];
     __shared__ double scale[16];
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     __syncthreads();
     double cj[K];
 #pragma unroll
-    for (int a = 0; a < K; ++a) cj[a] = (j < d) ? model[MODEL_HDR + (int64_t)j * K + a] : 0.0;
+    for (int a = 0; a < K; ++a) cj[a] = (j < d) ? C(j, a) : 0.0;
     {
         double rn = 0.0;
 #pragma unroll
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
         qscale[16 * t + j] = sc;
         if (mx > 0.0) {
             const double eps = 0.5 * sc;  // rounding bound of one entry: 2^(E_c - 63)
-            const double s2m = model[1], rmin = __longlong_as_double((long long)rmin_bits);
+            const double rmin = __longlong_as_double((long long)rmin_bits);
             const bool fwd = (double)K * (double)d * eps <= QGUARD_FWD * s2m;
             const bool bwd = (double)(K * K) * eps <= QGUARD_BWD * rmin;
             if (!(fwd || bwd)) atomicOr(&bad, 1);
@@ -133,38 +133,41 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
     __syncthreads();
     if (j == 0) qflag[t] = bad;
     if constexpr (K <= FUSED_MAX_K) {
-        // Slots 8 / 9 are the fused pass's run-again flag and the W-side verdict (wguard_kernel).  ONLY in the fused layout: at
-        // k = 16 this kernel has nine blocks and block 8 files its own tile's verdict in qflag[8] -- an unconditional reset by
+        // Slots 8.. belong to the fused pass's second stage (reduce_wguard_kernel) ONLY in the fused layout: at k = 16 this kernel
+        // has nine blocks and block 8 files its own tile's verdict in qflag[8] -- round 4's unconditional reset of slots 8 / 9 by
         // block 0 raced with it and could clear the flag of the tile holding column pairs (15, 8..15) (advisor, round 4).
         // Tiles this state size does not have are cleared too: ppca_em_last_guard reads the first four flags whatever the k of
         // the last pass, and the buffer may have held a larger model's (or the two-kernel pass's) flags.
         static_assert(Cfg<K>::NTP <= 8, "slots 8 / 9 must not alias a tile flag");
-        if (j == 0 && t == 0) {
-            qflag[8] = qflag[9] = 0;
+        // (slots 8..15 -- QF_* in ppca_internal.hpp -- are reduce_wguard_kernel's: every one is written before it is read, except
+        //  its ticket counter, which the host zeroes with the buffer and the kernel's last workgroup resets)
+        if (j == 0 && t == 0)
             for (int u = (K * (K + 1) / 2 + 15) / 16; u < 8; ++u) qflag[u] = 0;
-        }
     }
     // zero-padded copy of C: ppca_em9.hip (and em8's -DE8_C_GLOBAL experiment) read the B operands of b = X~ C from it.  Only
     // in the layout of fused_qtab_layout (k <= FUSED_MAX_K: the copy sits behind the largest table); the callers with their
     // own, exactly sized tables (ppca_em16.hip's, k = 11..16) have no room behind them -- round 4 found that the hard way:
     // the copy went over the two-kernel pass's workspace.
-    if (t == 0 && K <= FUSED_MAX_K) {
+    if constexpr (K <= FUSED_MAX_K) {  // (every block writes its share: block 0 alone was the kernel's tail)
+        constexpr int NB = Cfg<K>::NTP;
         double *cp = reinterpret_cast<double *>(qtab + qtab_bytes<FUSED_MAX_K>());
-        for (int idx = j; idx < FUSED_MAX_D * (K + 1); idx += 256) {
+        for (int idx = 256 * t + j; idx < FUSED_MAX_D * (K + 1); idx += 256 * NB) {
             const int jj = idx / (K + 1), a2 = idx - jj * (K + 1);
-            cp[idx] = (jj < d && a2 < K) ? model[MODEL_HDR + (int64_t)jj * K + a2] : 0.0;
+            cp[idx] = (jj < d && a2 < K) ? C(jj, a2) : 0.0;
         }
-        // ... and C in the operand order of em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (ppca_internal.hpp, CPB_DOUBLES): one
-        // contiguous 256-byte block per (dimension half, step, column group)
+#ifdef PPCA_WITH_CPB
+        // ... and C in the operand order of em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (-DE9_B444=1 experiment; ppca_internal.hpp,
+        // CPB_DOUBLES): one contiguous 256-byte block per (dimension half, step, column group)
         double *cb = cp + FUSED_MAX_D * (FUSED_MAX_K + 1);
         constexpr int NCGB = (K + 3) / 4;
-        for (int idx = j; idx < 2 * 16 * NCGB * 32; idx += 256) {
+        for (int idx = 256 * t + j; idx < 2 * 16 * NCGB * 32; idx += 256 * NB) {
             const int e = idx & 31, blk = idx >> 5;
             const int c = blk % NCGB, q = (blk / NCGB) & 15, kq = blk / (NCGB * 16);
             const int i = e & 3, kb = (e >> 2) & 1, kk = e >> 3;
             const int dim = 128 * kq + 32 * (q >> 2) + 16 * kb + 4 * (q & 3) + kk, col = 4 * c + i;
-            cb[idx] = (dim < d && col < K) ? model[MODEL_HDR + (int64_t)dim * K + col] : 0.0;
+            cb[idx] = (dim < d && col < K) ? C(dim, col) : 0.0;
         }
+#endif
     }
     const int lane = j & 63, kc = j >> 6;
     const int c = 16 * t + (lane & 15);
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
         const int kk = j0 + jj;
         const int jd = 128 * (kk >> 7) + 2 * (kk & 63) + ((kk >> 6) & 1);
         double q = 0.0;
-        if (c < KP && jd < d) q = model[MODEL_HDR + (int64_t)jd * K + a] * model[MODEL_HDR + (int64_t)jd * K + b];
+        if (c < KP && jd < d) q = C(jd, a) * C(jd, b);
         if (!(fabs(q) < 1.0e300)) q = 0.0;
         long long I = llrint(ldexp(q, shift));  // |I| <= 2^(QB QS - 2)
 #pragma unroll
@@ -197,6 +200,10 @@ __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, 
 #pragma unroll
     for (int sl = 0; sl < QS; ++sl)
         reinterpret_cast<i4_t *>(qtab)[(((size_t)t * QS + sl) * 4 + kc) * 64 + lane] = dg.v[sl];
+}
+template <int K>
+__global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, double *qscale, signed char *qtab, int *qflag) {
+    qprep_body<K>([=](int j, int a) { return model[MODEL_HDR + (int64_t)j * K + a]; }, model[1], d, qscale, qtab, qflag);
 }
 
 // NW = waves per workgroup: 4 (one wave per SIMD, 512 registers each) or 8 (two waves per SIMD,
@@ -253,8 +260,14 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
     double *xxs = sm + cfg::OFF_S;
 
-    if (!GI8 && p.runflag) {  // second stage of a guarded EM pass: wguard_kernel's verdict (Gram flags or the W-side check)
-        if (*p.runflag == 0) return;
+    const int *prows = p.rows;
+    const double *pw = p.w;
+    const int *pndev = p.n_dev;
+    const int64_t pn = p.n;
+    int fb_mode = 0;  // second stage of a guarded EM pass: reduce_wguard_kernel's verdict (Gram flags or the W-side check)
+    if (!GI8 && p.runflag) {
+        fb_mode = *p.runflag;
+        if (fb_mode == 0) return;
     } else if (p.qflag) {  // Gram engine chosen per model by qprep's dynamic-range guard: exactly one of the two variants runs
         int unsafe = 0;
 #pragma unroll
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bases stay in SGPRs
     const int l15 = lane & 15, l4 = lane >> 4;
     const int d = p.d;
-    const int64_t n = p.n_dev ? (int64_t)*p.n_dev : p.n;
+    const int64_t n = pndev ? (int64_t)*pndev : pn;
     const double *mC = p.model + MODEL_HDR;
     const double *mMean = mC + (int64_t)d * K;
     const double s2 = p.model[1], lnsig = p.model[2];
@@ -341,8 +354,24 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     // Each workgroup walks a CONTIGUOUS run of tiles (consecutive 64 KB pieces of X share pages, unlike a
     // grid-strided walk that starts every tile 16 MB further on).
     const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
-    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+    int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+    if (!GI8 && fb_mode == 2) {
+        // Only the slices of the flagged workgroups of the guarded launch (same grid: slice g = tiles [g tpw, (g + 1) tpw)), each
+        // split over gridDim.x / n_flagged workgroups of this one: a workgroup's run stays inside ONE slice, so everything below
+        // (descriptors relative to the run's first row, weights, gather list) is the plain pass's.
+        const int nfl = p.runflag[QF_NFLAGGED - QF_MODE];
+        const int wps = (int)gridDim.x / nfl, f = (int)blockIdx.x / wps, sub = (int)blockIdx.x - f * wps;
+        if (f >= nfl) {
+            tile_begin = tile_end = 0;
+        } else {
+            const int64_t s0 = (int64_t)p.who[f] * tiles_per_wg, s1 = s0 + tiles_per_wg < ntiles ? s0 + tiles_per_wg : ntiles;
+            const int64_t per = (s1 - s0 + wps - 1) / wps;
+            tile_begin = s0 + (int64_t)sub * per;
+            tile_end = tile_begin + per < s1 ? tile_begin + per : s1;
+            if (tile_begin > tile_end) tile_begin = tile_end;
+        }
+    }
     const int64_t nleft = n - tile_begin * B;
     const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));  // rows from the workgroup's first row to the end
     const double *Xwg = p.X + tile_begin * B * p.ldx;
@@ -350,7 +379,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
     const int64_t own = (tile_end - tile_begin) * B;
     const int nmine = tile_end > tile_begin ? (int)(own < nleft ? own : nleft) : 0;
     constexpr bool CAN_GATHER = EM && NW == 4 && (GATHER || !GI8);
-    const int *rows_wg = (CAN_GATHER && p.rows) ? p.rows + tile_begin * B : nullptr;
+    const int *rows_wg = (CAN_GATHER && prows) ? prows + tile_begin * B : nullptr;
     const int lane_entry = lane;
     // Row loads are buffer loads through ONE descriptor per tile (base = the tile's first row, extent = its real rows;
     // rows are contiguous, ldx == d): the row is a scalar offset, the lane offset one constant VGPR, the half an
@@ -507,7 +536,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             if constexpr (EM) {
                 // wave-uniform: a real row of one of THIS workgroup's tiles (32-bit compare on the scalar unit)
                 const bool mine = (int)(t - tile_begin) * B + ri < nmine;
-                const double wr = mine ? (p.w ? p.w[t * B + ri] : 1.0) : 0.0;  // (scalar load)
+                const double wr = mine ? (pw ? pw[t * B + ri] : 1.0) : 0.0;  // (scalar load)
                 xx_run += wr * pc_xx;
             }
         }
@@ -733,7 +762,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
             const int64_t row = tile * B + i;
             const double *g0 = Gp + i * GS;
             const double *g1 = g0 + B * GS;
-            const double wgt = (row < n) ? (p.w ? p.w[row] : 1.0) : 0.0;
+            const double wgt = (row < n) ? (pw ? pw[row] : 1.0) : 0.0;
             // observed count of the sample: popcount of its four mask words (the padding past d is never set)
             const int m = __popcll(Msc[i * 4]) + __popcll(Msc[i * 4 + 1]) + __popcll(Msc[i * 4 + 2]) + __popcll(Msc[i * 4 + 3]);
             double *wrow = Ws + i * WS;
@@ -810,7 +839,7 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
                 }
                 if constexpr (EM) {
                     const double lk0 = sample_llk_nolog(xx, quad, inv_s2, lnsig, m, K);
-                    if (p.w) {
+                    if (pw) {
                         if (!p.no_llk) sc_llk += wgt * (m > 0 ? lk0 - 0.5 * Posterior<K>::logdet(pm, pe) : 0.0);
                     } else {
                         const bool use = m > 0 && row < n;  // wgt is 1 for real rows
@@ -1346,54 +1375,182 @@ __global__ __launch_bounds__(64 * NW) void pass_kernel(PassArgs p) {
 // magnitudes (|P_ab| <= sqrt(P_aa P_bb), z_a^2 <= P_aa).
 constexpr double WGUARD_TOL = 5.820766091346741e-11;  // 2^-34
 
+// (round 5) The verdict used to send the WHOLE pass to the fp64 engine: one outlier row in ten million tripled the step.  The
+// bound is a sum over workgroups and almost all of it comes from the few whose exponents the large rows lifted, so the
+// second stage recomputes only those: with S_min,a = the smallest |S_j,aa| over the observed dimensions, workgroup g is
+// flagged when e_aa[g] > S_min,a 2^-34 / (2 grid) for some a -- what is left un-flagged then sums to at most half the
+// bound every diagonal entry has to clear.  The fp64 instantiation of the pass then walks only the flagged workgroups'
+// slices (runs of tiles: ppca_em9.hip deals them as this kernel recomputes them), each split over grid / n_flagged of its
+// workgroups, and the reduction is redone from the un-flagged partials + the fallback's (launch_em_fallback).  A model that
+// tripped the Gram guard, or more than half the grid flagged: the whole pass again, as before.
+//
+// One launch does the reduction AND the verdict: workgroups [0, ceil(len / 64)) sum the statistics (out[e] = the fixed order of
+// reduce_partials_kernel, bit-identical to it), two more sum the columns of the bounds; every workgroup takes a ticket after
+// its sums are visible (the storing wave's __threadfence: the release; the atomic; __threadfence in the last one: the acquire
+// -- a CU's L1 is never refreshed by another CU's stores), the holder of the last ticket runs the check.
 template <int K>
-__global__ __launch_bounds__(1024) void wguard_kernel(const double *stats, const double *errb, int grid, int d, int *qflag) {
+__global__ __launch_bounds__(256) void reduce_wguard_kernel(const double *part, int64_t len, double *out, GuardArgs g) {
     constexpr int KP = Cfg<K>::KP, NTP = Cfg<K>::NTP;
-    constexpr int NS = 12;  // slices of the workgroups per column: 12 x 80 = 960 threads sum ~grid / 12 bounds each
-    __shared__ double es[W_GUARD_NCOL];
-    __shared__ double parts[NS][W_GUARD_NCOL];
-    const int t = threadIdx.x;
-    if (t < NS * W_GUARD_NCOL) {
-        const int c = t % W_GUARD_NCOL, s0 = t / W_GUARD_NCOL;
-        double v0 = 0.0, v1 = 0.0;
-        if (errb) {
-            int b = s0;
-            for (; b + NS < grid; b += 2 * NS) {
-                v0 += errb[(int64_t)b * W_GUARD_NCOL + c];
-                v1 += errb[(int64_t)(b + NS) * W_GUARD_NCOL + c];
+    __shared__ double red[4][64];
+    __shared__ int last_s;
+    const int tid = threadIdx.x;
+    const int nstat = (int)((len + 63) / 64);
+    {
+        const bool bounds = (int)blockIdx.x >= nstat;  // the two extra workgroups: es[c] = sum_g errb[g][c]
+        const int gq = tid >> 6, l = tid & 63;
+        const int64_t e = bounds ? (int64_t)(blockIdx.x - nstat) * 64 + l : (int64_t)blockIdx.x * 64 + l;
+        const int64_t elen = bounds ? W_GUARD_NCOL : len;
+        const double *src = bounds ? g.errb : part;
+        const int per = (g.grid + 3) / 4;
+        const int p0 = gq * per, p1 = (p0 + per < g.grid) ? p0 + per : g.grid;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (e < elen && src) {
+            int q = p0;
+            for (; q + 4 <= p1; q += 4) {
+                s0 += src[(int64_t)q * elen + e];
+                s1 += src[(int64_t)(q + 1) * elen + e];
+                s2 += src[(int64_t)(q + 2) * elen + e];
+                s3 += src[(int64_t)(q + 3) * elen + e];
             }
-            if (b < grid) v0 += errb[(int64_t)b * W_GUARD_NCOL + c];
+            for (; q < p1; ++q) s0 += src[(int64_t)q * elen + e];
         }
-        parts[s0][c] = v0 + v1;
+        red[gq][l] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (gq == 0) {
+            // Handed to the last workgroup WITHOUT a release / acquire pair (311 agent-scope releases -- an L2 write-back each -- cost
+            // ~10 us of this 20 us kernel): every store of the handed-off values is an sc1 store (written through to memory),
+            // drained by the storing wave before the ticket, and every load of them below is an sc1 load (served past the L1 and
+            // the reader's own L2) -- the form MI355X_MICROARCH.md lists as valid in place of the fences.
+            if (e < elen) __hip_atomic_store((bounds ? g.es : out) + e, (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (s_waitcnt vmcnt(0): the stores have left)
+        }
     }
     __syncthreads();
-    if (t < W_GUARD_NCOL) {
-        double v = 0.0;
+    if (tid == 0) last_s = atomicAdd(&g.qflag[QF_TICKET], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last_s) return;
+    auto ld = [](const double *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+    // ---------------------------------------------------------------- the verdict (one workgroup)
+    __shared__ double es[W_GUARD_NCOL];
+    __shared__ unsigned long long smin[K];
+    __shared__ int nflag_s;
+    __shared__ unsigned char fl[1024];
+    int gram = 0;
 #pragma unroll
-        for (int u = 0; u < NS; ++u) v += parts[u][t];  // (fixed order)
-        es[t] = v;
+    for (int u = 0; u < NTP; ++u) gram |= g.qflag[u];
+    auto finish = [&](int mode, int verdict, int nflag, int nrows2) {
+        if (tid == 0) {
+            g.qflag[QF_MODE] = mode;
+            g.qflag[QF_WVERDICT] = verdict;
+            g.qflag[QF_NFLAGGED] = nflag;
+            g.qflag[QF_NROWS2] = nrows2;
+            g.qflag[QF_GVERDICT] = gram ? 1 : 0;
+            g.qflag[QF_TICKET] = 0;  // (the next launch's election)
+        }
+    };
+    auto flag_all = [&]() {
+        for (int w = tid; w < g.grid; w += 256) g.wgflag[w] = 1;
+    };
+    if (gram) {  // the int8 kernel returned at once: its partials (and `out`) hold nothing
+        flag_all();
+        finish(1, 0, g.grid, 0);
+        return;
     }
+    if (!g.errb) {
+        finish(0, 0, 0, 0);
+        return;
+    }
+    if (tid < W_GUARD_NCOL) es[tid] = ld(g.es + tid);
+    if (tid < K) smin[tid] = 0x7FF0000000000000ull;  // + inf
+    if (tid == 0) nflag_s = 0;
     __syncthreads();
     int unsafe = 0;
-    if (errb && t < d) {
-        const StatsLayout L(d, K);
-        const double tot = stats[L.totals + t];
-        if (tot != 0.0) {
+    const StatsLayout L(g.d, K);
+    for (int j = tid; j < g.d; j += 256) {
+        if (ld(out + L.totals + j) != 0.0) {
 #pragma unroll
             for (int a = 0; a < K; ++a) {
-                const double S = stats[L.S + (int64_t)t * KP + tri(a, a)];
-                if (fabs(S) * WGUARD_TOL < es[tri(a, a)]) unsafe = 1;  // (a NaN statistic compares false: it propagates as through fp64)
+                const double S = fabs(ld(out + L.S + (int64_t)j * KP + tri(a, a)));
+                if (S * WGUARD_TOL < es[tri(a, a)]) unsafe = 1;  // (a NaN statistic compares false: it propagates as through fp64)
             }
         }
     }
     unsafe = __syncthreads_or(unsafe);
-    if (t == 0) {
-        int gram = 0;
-#pragma unroll
-        for (int u = 0; u < NTP; ++u) gram |= qflag[u];
-        qflag[8] = (gram | unsafe) ? 1 : 0;
-        qflag[9] = unsafe ? 1 : 0;
+    if (!unsafe) {
+        finish(0, 0, 0, 0);
+        return;
     }
+    // which workgroups' cuts the bound is made of (the cold path from here on)
+    for (int j = tid; j < g.d; j += 256) {
+        if (ld(out + L.totals + j) != 0.0) {
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+                const double S = fabs(ld(out + L.S + (int64_t)j * KP + tri(a, a)));
+                if (S == S) atomicMin(&smin[a], (unsigned long long)__double_as_longlong(S));  // (non-negative doubles order like their bits)
+            }
+        }
+    }
+    __syncthreads();
+    for (int w = tid; w < g.grid; w += 256) {
+        int f = 0;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const double sm_a = __longlong_as_double((long long)smin[a]);
+            if (g.errb[(int64_t)w * W_GUARD_NCOL + tri(a, a)] * (2.0 * (double)g.grid) > sm_a * WGUARD_TOL) f = 1;
+        }
+        g.wgflag[w] = f;
+        if (w < 1024) fl[w] = (unsigned char)f;  // (the list below is built from LDS: no global round trip inside the workgroup)
+        if (f) atomicAdd(&nflag_s, 1);
+    }
+    __syncthreads();
+    const int nflag = nflag_s;
+    if (nflag == 0 || 2 * nflag > g.grid || g.grid > 1024) {
+        __syncthreads();
+        flag_all();
+        finish(1, 1, g.grid, 0);
+        return;
+    }
+    // the flagged workgroups, ascending (one thread: at most grid / 2 entries), and the rows of their slices
+    if (tid == 0) {
+        const int64_t n = g.n_dev ? (int64_t)*g.n_dev : g.n;
+        const int64_t ntiles = (n + FUSED_TILE - 1) / FUSED_TILE;
+        const int64_t per_wg = (ntiles + g.grid - 1) / g.grid * FUSED_TILE;
+        int at = 0;
+        int64_t rows = 0;
+        for (int w = 0; w < g.grid; ++w) {
+            if (fl[w]) {
+                g.who[at++] = w;
+                const int64_t r0 = (int64_t)w * per_wg, r1 = r0 + per_wg < n ? r0 + per_wg : n;
+                rows += r1 > r0 ? r1 - r0 : 0;
+            }
+        }
+        nflag_s = (int)(rows < 0x7FFFFFFF ? rows : 0x7FFFFFFF);
+    }
+    __syncthreads();
+    finish(2, 1, nflag, nflag_s);
+}
+
+// Second reduction of a guarded EM pass (behind the mode flag): the un-flagged workgroups' partials of the int8 kernel + the
+// partials of the fp64 fallback, each in the fixed order of reduce_partials_kernel.
+__global__ __launch_bounds__(256) void reduce_fallback_kernel(const double *part, const double *part2, const int *wgflag, int grid_parts,
+                                                              int64_t len, double *out, const int *run_if) {
+    __shared__ double red[4][64];
+    if (*run_if == 0) return;
+    const int gq = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 64 + l;
+    const int per = (grid_parts + 3) / 4;
+    const int p0 = gq * per, p1 = (p0 + per < grid_parts) ? p0 + per : grid_parts;
+    double s0 = 0.0, s1 = 0.0;
+    if (e < len) {
+        for (int q = p0; q < p1; ++q) {
+            if (!wgflag[q]) s0 += part[(int64_t)q * len + e];
+            s1 += part2[(int64_t)q * len + e];
+        }
+    }
+    red[gq][l] = s0 + s1;
+    __syncthreads();
+    if (gq == 0 && e < len) out[e] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
 
 
@@ -1426,10 +1583,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *part
     }
 }
 
-// M-step finalisation (ppca_model.rs:307-322, :360-377) -- one workgroup.
+// M-step finalisation (ppca_model.rs:307-322, :360-377) -- one workgroup.  write: this workgroup stores the new model; cn_lds /
+// s2_lds (nullable): the new transform (row-major [d][K]) and sigma^2 also into LDS (finalize_qprep_kernel: every workgroup
+// finalises redundantly, then builds its tile of the new model's slice table from there).
 template <int K>
-__global__ __launch_bounds__(256) void finalize_kernel(const double *stats, const double *min, double *mout, int d,
-                                                       double tau, int has_ig, double alpha, double beta) {
+__device__ __forceinline__ void finalize_body(const double *stats, const double *min, double *mout, int d, double tau, int has_ig,
+                                              double alpha, double beta, bool write, double *cn_lds, double *s2_lds) {
     constexpr int KP = K * (K + 1) / 2;
     StatsLayout L(d, K);
     __shared__ double red[256];
@@ -1464,19 +1623,46 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *stats, cons
             cz += cn[a] * stats[L.U + (int64_t)j * K + a];
         }
         row_solve<K>(S, tau, rhs, cn);
+        if (cn_lds) {
 #pragma unroll
-        for (int a = 0; a < K; ++a) Cnew[(int64_t)j * K + a] = cn[a];
-        const double tot = stats[L.totals + j];
-        const double totdev = stats[L.sumx + j] - cz;  // sum_i w_i m_ij (x_ij - c_j.z_i - mu_j)  (:338-347)
-        Mnew[j] = (tot > 0.0 ? totdev / tot : 0.0) + Mold[j];  // :373-377
+            for (int a = 0; a < K; ++a) cn_lds[j * K + a] = cn[a];
+        }
+        if (write) {
+#pragma unroll
+            for (int a = 0; a < K; ++a) Cnew[(int64_t)j * K + a] = cn[a];
+            const double tot = stats[L.totals + j];
+            const double totdev = stats[L.sumx + j] - cz;  // sum_i w_i m_ij (x_ij - c_j.z_i - mu_j)  (:338-347)
+            Mnew[j] = (tot > 0.0 ? totdev / tot : 0.0) + Mold[j];  // :373-377
+        }
     }
+    const double sig = sqrt(s2new);  // :389
     if (tid == 0) {
-        const double sig = sqrt(s2new);  // :389
-        mout[0] = sig;
-        mout[1] = sig * sig;
-        mout[2] = log(sig);
-        mout[3] = 0.0;
+        if (write) {
+            mout[0] = sig;
+            mout[1] = sig * sig;
+            mout[2] = log(sig);
+            mout[3] = 0.0;
+        }
+        if (s2_lds) *s2_lds = sig * sig;  // (what the model buffer holds: the passes read sigma^2 from there)
     }
+}
+template <int K>
+__global__ __launch_bounds__(256) void finalize_kernel(const double *stats, const double *min, double *mout, int d,
+                                                       double tau, int has_ig, double alpha, double beta) {
+    finalize_body<K>(stats, min, mout, d, tau, has_ig, alpha, beta, true, nullptr, nullptr);
+}
+// The plain EM step's finalisation AND the next pass's qprep_kernel in one launch: grid = the packed-column tiles of the slice
+// table; every workgroup finalises (d row systems, one per thread: redundant and concurrent), workgroup 0 stores the model, then
+// each builds its tile of the table, its guard flag and its share of the padded copy of C from the new transform in LDS.
+template <int K>
+__global__ __launch_bounds__(256) void finalize_qprep_kernel(const double *stats, const double *min, double *mout, int d, double tau,
+                                                             int has_ig, double alpha, double beta, double *qscale, signed char *qtab,
+                                                             int *qflag) {
+    __shared__ double cn[FUSED_MAX_D * K];
+    __shared__ double s2n;
+    finalize_body<K>(stats, min, mout, d, tau, has_ig, alpha, beta, blockIdx.x == 0, cn, &s2n);
+    __syncthreads();
+    qprep_body<K>([&](int j, int a) { return cn[j * K + a]; }, s2n, d, qscale, qtab, qflag);
 }
 
 // ------------------------------------------------------------------ synthetic data
@@ -1550,6 +1736,17 @@ __global__ void canon_copy_kernel(const double *src, double *dst, int64_t n) {
     } else if (i < n) {
         dst[i] = __builtin_isfinite(src[i]) ? src[i] : __builtin_nan("");
     }
+}
+// X[rows[i]][:] *= factor (bench / test hook: outlier rows in a device-resident dataset; non-finite entries stay masked)
+__global__ void scale_rows_kernel(double *X, int64_t ldx, int d, const int64_t *rows, int64_t n_rows, double factor) {
+    const int64_t i = blockIdx.x;
+    if (i >= n_rows) return;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) X[rows[i] * ldx + j] *= factor;
+}
+hipError_t launch_scale_rows(double *X, int64_t ldx, int d, const int64_t *rows_dev, int64_t n_rows, double factor, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, s, X, ldx, d, rows_dev, n_rows, factor);
+    return hipGetLastError();
 }
 hipError_t launch_canon_copy(const double *src, double *dst, int64_t n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
@@ -1800,7 +1997,7 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
         return launch_pass_t<K, EM, 4, false>(grid, a, s);
     }
 #endif
-    hipLaunchKernelGGL((qprep_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab, a.qflag);
+    if (!a.skip_qprep) hipLaunchKernelGGL((qprep_kernel<K>), dim3(Cfg<K>::NTP), dim3(256), 0, s, a.model, a.d, a.qscale, a.qtab, a.qflag);
     auto int8_pass = [&](const PassArgs &b) {
         if constexpr (!EM) {  // llk / llks alone: the two-tile sweep (ppca_llk.hip) unless PPCA_LLK2=0
             if (!b.states && !b.covs && !b.recon && llk2_enabled()) return launch_llk2(K, grid, b, s);
@@ -1855,20 +2052,39 @@ hipError_t launch_pass_em(int k, int grid, const PassArgs &a, hipStream_t s) {
     PPCA_DISPATCH_K(k, return (launch_pass_guarded<KK, true>(grid, a, s)));
     return hipErrorInvalidValue;
 }
-hipError_t launch_em_wguard(int k, int grid, PassArgs a, const double *stats, hipStream_t s, const int **runflag_out) {
-    *runflag_out = nullptr;
+hipError_t launch_reduce_wguard(int k, const double *part, int64_t len, double *stats, const GuardArgs &g, hipStream_t s, bool *applies_out) {
+    *applies_out = false;
 #ifdef PPCA_DEV_K10
-    return hipSuccess;  // kernel-tuning builds instantiate the int8 variants only
+    return launch_reduce_partials(part, g.grid, len, stats, s);  // kernel-tuning builds instantiate the int8 variants only
 #else
-    if (gram_mode() != 0) return hipSuccess;  // engine pinned: nothing to decide
-    const double *errb = (em8_enabled() && em8_covers(k)) ? a.errb : nullptr;  // (only em8_kernel / em9_kernel cut their rows)
-    a.runflag = a.qflag + 8;
-    *runflag_out = a.runflag;
+    if (gram_mode() != 0) return launch_reduce_partials(part, g.grid, len, stats, s);  // engine pinned: nothing to decide
+    *applies_out = true;
+    GuardArgs h = g;
+    if (!(em8_enabled() && em8_covers(k))) h.errb = nullptr;  // (only em8_kernel / em9_kernel cut their rows)
+    const int blocks = (int)((len + 63) / 64) + (W_GUARD_NCOL + 63) / 64;
     PPCA_DISPATCH_K(k, {
-        hipLaunchKernelGGL((wguard_kernel<KK>), dim3(1), dim3(1024), 0, s, stats, errb, grid, a.d, a.qflag);
-        return (launch_pass_t<KK, true, 4, false>(grid, a, s));
+        hipLaunchKernelGGL((reduce_wguard_kernel<KK>), dim3(blocks), dim3(256), 0, s, part, len, stats, h);
+        return hipGetLastError();
     });
     return hipErrorInvalidValue;
+#endif
+}
+hipError_t launch_em_fallback(int k, int grid, PassArgs a, const GuardArgs &g, const double *part, double *part2, int64_t len, double *stats,
+                              hipStream_t s) {
+#ifdef PPCA_DEV_K10
+    return hipSuccess;
+#else
+    a.runflag = g.qflag + QF_MODE;
+    a.who = g.who;
+    a.part = part2;
+    a.errb = nullptr;
+    PPCA_DISPATCH_K(k, {
+        if (hipError_t e = launch_pass_t<KK, true, 4, false>(grid, a, s); e != hipSuccess) return e;
+    });
+    const int blocks = (int)((len + 63) / 64);
+    hipLaunchKernelGGL(reduce_fallback_kernel, dim3(blocks), dim3(256), 0, s, part, (const double *)part2, (const int *)g.wgflag, grid, len, stats,
+                       (const int *)(g.qflag + QF_MODE));
+    return hipGetLastError();
 #endif
 }
 
@@ -1916,6 +2132,13 @@ hipError_t launch_finalize(int k, int d, const double *stats, const double *mode
                            int has_ig, double alpha, double beta, hipStream_t s) {
     PPCA_DISPATCH_K(k, hipLaunchKernelGGL((finalize_kernel<KK>), dim3(1), dim3(256), 0, s, stats, model_in, model_out,
                                           d, tau, has_ig, alpha, beta));
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_qprep(int k, int d, const double *stats, const double *model_in, double *model_out, double tau, int has_ig,
+                                 double alpha, double beta, const PassArgs &tab, hipStream_t s) {
+    PPCA_DISPATCH_K(k, hipLaunchKernelGGL((finalize_qprep_kernel<KK>), dim3(Cfg<KK>::NTP), dim3(256), 0, s, stats, model_in, model_out, d,
+                                          tau, has_ig, alpha, beta, tab.qscale, tab.qtab, tab.qflag));
     return hipGetLastError();
 }
 

@@ -326,6 +326,11 @@ def test_outlier_row_sends_the_statistics_to_fp64(P, oracle, ctx, k, d):
         xo[100] *= 1e6
         got, want = _stats(P, P.Dataset(xo), m), oracle.stats(xo, s, c, mu)
         assert (ctx.last_guard() == (0, 1)) if k <= 10 else (ctx.debug_counters()[7] >= 1), cap
+        if k <= 10:
+            # full grid (188 workgroups of one tile): only the outlier's workgroup is recomputed -- 32 rows; one workgroup: it IS
+            # the whole pass
+            mode, wgs, rows, _ = ctx.last_fallback()
+            assert (mode, wgs, rows) == ((2, 1, 32) if cap == 0 else (1, 1, 0)), (cap, mode, wgs, rows)
         _assert_stats(got, want, d, k, 1e-9, (k, cap, "outlier"))
         Sg, Sw = got[d * k:d * k + d * kp].reshape(d, kp), want[d * k:d * k + d * kp].reshape(d, kp)
         masked = ~np.isfinite(xo[100])
@@ -335,6 +340,107 @@ def test_outlier_row_sends_the_statistics_to_fp64(P, oracle, ctx, k, d):
         s1, _, _ = oracle.iterate(xo, s, c, mu)
         new = m.iterate(P.Dataset(xo))
         assert abs(new.isotropic_noise - s1) < 1e-9 * s1 and np.isfinite(new.transform).all()
+
+
+@pytest.mark.parametrize("k", [4, 10])
+def test_outlier_rows_cost_their_workgroups_slices(P, oracle, ctx, k):
+    """The second stage of the guarded EM pass (round 5; ppca_kernels.hip, reduce_wguard_kernel): the last workgroup of the
+    reduction flags the workgroups whose cut dominates the rounding bound, writes their slices out as a gather list, and the
+    fp64 instantiation of the pass walks that list with the whole grid; the statistics are re-reduced from the un-flagged
+    partials + the fallback's.  N = 20 000 on 8 workgroups (79 tiles each) with three outlier rows in two of them: mode 2,
+    two workgroups, 2 x 79 x 32 rows, every block within 1e-9 of the literal oracle (ppca_model.rs:277-358) -- un-weighted,
+    weighted (the list carries the rows' weights) and as a GATHERED component pass of the mixture (the list composes with the
+    pass's own gather list); two runs bit-identical; more flagged workgroups than half the grid: the whole pass again."""
+    n, d = 20000, 256
+    rng = np.random.default_rng(50 + k)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 17 + k)
+    c, mu, s = 0.5 * rng.standard_normal((d, k)), 0.1 * rng.standard_normal(d), 0.7
+    m = P.PPCAModel(s, c, mu)
+    w = rng.uniform(0.25, 2.0, n)
+    ctx.set_grid_limit(8)
+    per_wg = -(-(-(-n // 32)) // 8) * 32  # ceil(ceil(n / 32) / 8) tiles of 32 rows
+    xo = x.copy()
+    for r in (100, per_wg * 5 + 7, per_wg * 5 + 900):
+        xo[r] *= 1e6
+    for ww in (None, w):
+        ds = P.Dataset(xo, ww)
+        got = _stats(P, ds, m)
+        assert ctx.last_guard() == (0, 1)
+        mode, wgs, rows, _ = ctx.last_fallback()
+        assert (mode, wgs, rows) == (2, 2, 2 * per_wg), (mode, wgs, rows)
+        _assert_stats(got, oracle.stats(xo, s, c, mu, ww), d, k, 1e-9, (k, ww is None))
+        assert np.array_equal(got, _stats(P, ds, m))  # (fixed summation orders in both stages)
+        # the same rows without the outliers: nothing to do
+        _stats(P, P.Dataset(x, ww), m)
+        assert ctx.last_guard() == (0, 0) and ctx.last_fallback()[:3] == (0, 0, 0)
+    # gathered: a third of the rows dropped by their weight, the outliers among the kept ones
+    u = rng.uniform(-3.0, 0.0, n)
+    u[rng.random(n) < 0.33] = -1e4
+    u[[100, per_wg * 5 + 7, per_wg * 5 + 900]] = 0.0
+    got, _, used = _gathered_stats(P, ctx, P.Dataset(xo), m, u)
+    mode, wgs, rows, _ = ctx.last_fallback()
+    assert mode == 2 and 1 <= wgs <= 3 and used < n, (mode, wgs, used)
+    keep = u > -1e3
+    wk = np.exp(u[keep] - u.max())
+    want = oracle.stats(xo[keep], s, c, mu, wk)
+    for name, a, b in _blocks(d, k)[:-1]:
+        assert _rel(got[a:b], want[a:b]) < 1e-9, (name, k, "gathered")
+    assert _rel(got[[-8, -7, -5]], want[[-8, -7, -5]]) < 1e-9  # (a component pass skips the log-likelihood: PassArgs::no_llk)
+    # five of eight workgroups: more than half the grid -> the whole pass on the fp64 engine
+    xa = x.copy()
+    for g in range(5):
+        xa[per_wg * g + 11] *= 1e6
+    got = _stats(P, P.Dataset(xa), m)
+    assert ctx.last_fallback()[0] == 1
+    _assert_stats(got, oracle.stats(xa, s, c, mu), d, k, 1e-9, (k, "half the grid"))
+
+
+def test_slice_table_is_cached_per_model_content(P, oracle, ctx):
+    """A fused pass builds the int8 slice table / guard flags of its model (qprep_kernel) unless the context's table is already
+    that model's: the EM step's finalisation builds the NEW model's in the same launch (finalize_qprep_kernel), and a pass of the
+    model the previous pass used skips it too.  The cache key is (buffer, write stamp): alternating models, a model whose buffer
+    is re-used by a later step, and the guard's verdict for a model the cache served must all behave as with PPCA_QPREP_CACHE=0
+    (every pass builds its table) -- bit for bit."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import ppca_rs_amd as P
+from ppca_rs_amd import _lib
+from oracle import ppca_oracle as o
+o.build()
+x, _, _ = o.synth(3000, 200, 7, 0.3, 5)
+rng = np.random.default_rng(1)
+ds = P.Dataset(x)
+A = P.PPCAModel(0.8, 0.5 * rng.standard_normal((200, 7)), np.zeros(200))
+B = P.PPCAModel(0.3, rng.standard_normal((200, 7)), 0.1 * rng.standard_normal(200))
+cb = rng.standard_normal((200, 7)); cb[:100] *= 1e-4
+Bad = P.PPCAModel(1e-5, cb, np.zeros(200))  # (trips the Gram guard)
+out = [A.llk(ds), B.llk(ds), A.llk(ds), Bad.llk(ds), A.llk(ds)]
+m = A
+for _ in range(4):
+    m, l = m.iterate_with_llk(ds)
+    out += [l, m.isotropic_noise, float(np.abs(m.transform).sum())]
+out += [m.llk(ds), B.llk(ds)]
+m2, l2 = Bad.iterate_with_llk(ds)
+out += [l2, m2.isotropic_noise, _lib.default_context().last_guard()[0]]
+m3, l3 = m.iterate_with_llk(ds)
+out += [l3, m3.isotropic_noise, _lib.default_context().last_guard()[0]]
+np.save(sys.argv[1], np.array(out, dtype=np.float64))
+""" % root
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for env in ({}, {"PPCA_QPREP_CACHE": "0"}):
+            out = os.path.join(td, "o%d.npy" % len(res))
+            subprocess.run([sys.executable, "-c", code, out], check=True, env={**os.environ, **env}, timeout=600)
+            res.append(np.load(out))
+    assert np.array_equal(res[0], res[1]), (res[0], res[1])
+    assert res[0][-1] == 0 and res[0][-4] == 1  # (the cached table's flags are the model's own: Bad trips the guard, its successor's model does not)
 
 
 @pytest.mark.parametrize("k,d", [(4, 300), (20, 70)])
