@@ -687,6 +687,11 @@ struct I8GemmArgs {
     int64_t ksplit;    // 0 = no split
     int nsplit;
     double *out2;
+    // (round 5) XCD-aware tile order: a 1-D grid whose workgroup L (dispatched to XCD L % 8) takes column block (L % 8) + 8 j -- so
+    // a column stripe of B is only ever read through ONE XCD's L2 -- and, within the XCD, the tiles of one row block side by
+    // side (j fastest), then the next row block, then the next K-slice.  ncb / nrb: column / row blocks of the product.
+    int xcd_map;
+    int ncb, nrb;
 };
 
 // KB = bytes of K per staged step (64 or 128: whole 128-byte lines per row at 128); rows padded by 16 B in LDS.
@@ -695,15 +700,6 @@ struct I8GemmArgs {
 // BUF: operands through buffer descriptors (per-thread piece offsets computed once, the K position a scalar offset:
 // no vector address arithmetic in the K loop -- the pointer form spent 2.7 vector instructions per MFMA on 64-bit
 // addresses and bounds, SQ_INSTS_VALU 338 M against SQ_INSTS_MFMA 91 M per launch); needs both operands < 2 GiB.
-#ifndef I8_PIPE
-#define I8_PIPE 2  // 2: the K loop as a three-stage pipeline (round 5): three LDS buffers, the staging of step i + 2 and the global request
-                   // of step i + 3 between the MFMA batches of step i, the first fragments of step i + 1 requested before the
-                   // step's barrier; 1: the pipeline inside one step only (two buffers); 0: rounds 2-4 (all fragment reads, all MFMAs,
-                   // staging, request, barrier)
-#endif
-#ifndef I8_RAW_BARRIER
-#define I8_RAW_BARRIER 0
-#endif
 #ifndef I8_STAGES
 #define I8_STAGES 1  // measured at config 4 (round 2): 1 -> 254.0, 2 -> 253.4, 3 -> 253.2, 4 -> 262.4 ms (spills); the registers go to the fragments
 #endif
@@ -721,9 +717,8 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
     // 0.9-1.1e9 against SQ_ACTIVE_INST_LDS 0.4-0.6e9 per launch (round 2, gpurun_out/pmcgen).
     extern __shared__ __attribute__((aligned(16))) unsigned char i8sm[];
     constexpr int AROWS = TM, BROWS = GQS * 32;
-    constexpr int NBUF = (I8_PIPE == 2 && BUF) ? 3 : 2;
-    unsigned char *As = i8sm;                              // [NBUF][4][TM][16]
-    unsigned char *Bs = i8sm + NBUF * 4 * AROWS * 16;      // [NBUF][4][GQS * 32][16]
+    unsigned char *As = i8sm;                              // [2][4][TM][16]
+    unsigned char *Bs = i8sm + 2 * 4 * AROWS * 16;         // [2][4][GQS * 32][16]
     auto slot = [](int rows, int buf, int row, int q) {    // byte offset of (row, piece q) in buffer buf
         const int g = (q & 1) * 2 + (q >> 1) * 12;         // 0, 2, 12, 14
         return ((buf * 4 + q) * rows + (row ^ g)) * 16;
@@ -733,9 +728,19 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
     const int l15 = lane & 15, l4 = lane >> 4;
     // (an XCD-aware order of the tiles -- column block c pinned to XCD c % 8, row blocks of one column block side by
     //  side -- measured SLOWER, 106 vs 97 ms per iteration at N = 400 k, d = 1024, k = 64: plain 2-D order kept)
-    const int64_t m0 = (int64_t)blockIdx.y * TM;
-    const int64_t n0 = (int64_t)blockIdx.x * 32;
-    const int zs = g.ksplit > 0 ? (int)blockIdx.z : 0;
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    if (g.xcd_map) {
+        const int L = (int)blockIdx.x, xcd = L & 7, sq = L >> 3;
+        const int ncmax = (g.ncb + 7) >> 3, per_z = ncmax * g.nrb;
+        bz = sq / per_z;
+        const int s2 = sq - bz * per_z;
+        by = s2 / ncmax;
+        bx = xcd + 8 * (s2 - by * ncmax);
+        if (bx >= g.ncb) return;  // (the XCDs with one column block fewer)
+    }
+    const int64_t m0 = (int64_t)by * TM;
+    const int64_t n0 = (int64_t)bx * 32;
+    const int zs = g.ksplit > 0 ? bz : 0;
     const bool second = zs > 0;
     const int64_t kbeg = (int64_t)zs * g.ksplit;
     const int64_t kend = g.ksplit > 0 ? (kbeg + g.ksplit < g.K ? kbeg + g.ksplit : g.K) : g.K;
@@ -814,38 +819,7 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
             *reinterpret_cast<gi4_t *>(Bs + slot(BROWS, buf, piece / PR, piece % PR)) = rb[st][u];
         }
     };
-#if I8_PIPE
-    // (round 5) The K-step as a software pipeline inside the wave: the B fragments of slice pair p + 1 are requested before the
-    // eight MFMAs of pair p issue, so that from the second pair on the LDS reads run under the matrix pipe; the next step's
-    // staging (LDS stores of the rows fetched one step ago: `mid0`) goes behind the first pair's MFMAs and the global request of
-    // the step after it (`mid1`) behind the second.  Rounds 2-4 requested all twelve fragments, waited, issued the 32 MFMAs,
-    // staged, fetched, and met at the barrier: per step 1 130 cycles of MFMAs + 1 000 of LDS traffic took 3 400 --
-    // eight waves reading together, then multiplying together, then staging together.
-    auto compute = [&](int buf, auto &&mid0, auto &&mid1) {
-        gi4_t fa[4], fb[GQS];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const gi4_t *>(As + slot(AROWS, buf, 64 * wm + 16 * a + l15, l4));
-#pragma unroll
-        for (int s = 0; s < 2; ++s) fb[s] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, buf, s * 32 + 16 * wn + l15, l4));
-        static_for_g<GQS / 2>([&](auto p_tag) {
-            constexpr int p = decltype(p_tag)::value;
-            if constexpr (2 * p + 2 < GQS) {
-#pragma unroll
-                for (int s = 2 * p + 2; s < 2 * p + 4; ++s)
-                    fb[s] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, buf, s * 32 + 16 * wn + l15, l4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 2 * p; s < 2 * p + 2; ++s)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (p == 0) mid0();
-            if constexpr (p == 1) mid1();
-        });
-    };
-#else
-    auto compute = [&](int buf, auto &&mid0, auto &&mid1) {
+    auto compute = [&](int buf) {
         // every fragment of the K-step is requested before the first MFMA (12 reads in flight: the LDS latency is paid
         // once per step, not once per slice pair as hipcc schedules the interleaved form)
         gi4_t fa[4], fb[GQS];
@@ -859,73 +833,7 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mid0();
-        mid1();
     };
-#endif
-#if I8_PIPE == 2
-    if constexpr (BUF) {
-        // Step i contracts buffer i % 3 while it stages step i + 2 into buffer (i + 2) % 3 (last read in step i - 1: the barrier
-        // that ended it), requests step i + 3 from global memory and, after its last MFMAs have issued, already requests the first
-        // fragments of step i + 1 from buffer (i + 1) % 3 (staged during step i - 1, visible since the same barrier): the only
-        // LDS latency a step still waits for is hidden behind the previous step's MFMAs and the barrier.  Reads past K return
-        // zeros (buffer descriptors), so the tail needs no special case.
-        const int nsteps = (int)((kend - kbeg) / KB);
-        gi4_t fa[4], fb[GQS];
-        auto first_frags = [&](auto b_tag) {
-            constexpr int b = decltype(b_tag)::value;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const gi4_t *>(As + slot(AROWS, b, 64 * wm + 16 * a + l15, l4));
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) fb[s2] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, b, s2 * 32 + 16 * wn + l15, l4));
-        };
-        auto step = [&](auto b_tag, int i) {
-            constexpr int b = decltype(b_tag)::value;
-            static_for_g<GQS / 2>([&](auto p_tag) {
-                constexpr int p = decltype(p_tag)::value;
-                if constexpr (2 * p + 2 < GQS) {
-#pragma unroll
-                    for (int s2 = 2 * p + 2; s2 < 2 * p + 4; ++s2)
-                        fb[s2] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, b, s2 * 32 + 16 * wn + l15, l4));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s2 = 2 * p; s2 < 2 * p + 2; ++s2)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) acc[a][s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s2], acc[a][s2], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (p == 0) stash((b + 2) % 3, 0);                          // step i + 2
-                if constexpr (p == 1) fetch(kbeg + (int64_t)(i + 3) * KB, 0);         // step i + 3
-            });
-            first_frags(std::integral_constant<int, (b + 1) % 3>{});                  // step i + 1
-            __builtin_amdgcn_sched_barrier(0);
-#if I8_RAW_BARRIER
-            // s_barrier WITHOUT the s_waitcnt lgkmcnt(0) that __syncthreads() puts in front of it: this wave's only LDS stores of
-            // the step (the staging behind the first MFMA batch) were followed by fragment reads whose data the later batches have
-            // already consumed -- a wave's LDS operations complete in order, so the stores are done; what is still in flight are
-            // the six reads of the NEXT step's first fragments, from a buffer nobody writes before the barrier after this one.
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-#else
-            __syncthreads();
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        fetch(kbeg, 0);
-        stash(0, 0);
-        fetch(kbeg + KB, 0);
-        stash(1, 0);
-        fetch(kbeg + 2 * (int64_t)KB, 0);
-        __syncthreads();
-        first_frags(std::integral_constant<int, 0>{});
-        for (int i = 0; i < nsteps; i += 3) {
-            step(std::integral_constant<int, 0>{}, i);
-            if (i + 1 < nsteps) step(std::integral_constant<int, 1>{}, i + 1);
-            if (i + 2 < nsteps) step(std::integral_constant<int, 2>{}, i + 2);
-        }
-    } else
-#endif
     if constexpr (BUF) {
         // ST K-steps travel in registers while one is contracted out of LDS: a step is requested ST iterations (ST x
         // ~1 k cycles of MFMAs per SIMD) before it is staged.  (The MFMA pipe is 30 % busy in this kernel by
@@ -941,8 +849,9 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
             for (int j = 0; j < ST; ++j) {
                 if (i + j < nsteps) {  // (uniform)
                     const int buf = (i + j) & 1;
-                    compute(buf, [&] { stash(buf ^ 1, (j + 1) % ST); },                                       // step i + j + 1
-                            [&] { fetch(kbeg + (int64_t)(i + j + 1 + ST) * KB, (j + 1) % ST); });              // step i + j + 1 + ST
+                    compute(buf);
+                    stash(buf ^ 1, (j + 1) % ST);                                       // step i + j + 1
+                    fetch(kbeg + (int64_t)(i + j + 1 + ST) * KB, (j + 1) % ST);        // step i + j + 1 + ST
                     __syncthreads();
                 }
             }
@@ -955,7 +864,7 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
         for (int64_t k0 = kbeg; k0 < kend; k0 += KB) {
             const bool more = k0 + KB < kend;
             if (more) fetch(k0 + KB, 0);
-            compute(buf, [] {}, [] {});
+            compute(buf);
             if (more) stash(buf ^ 1, 0);
             __syncthreads();
             buf ^= 1;
@@ -2217,7 +2126,7 @@ __global__ void add_partial_kernel(double *out, int64_t ldo, const double *part,
 
 template <int TM, bool BUF>
 static hipError_t launch_i8gemm_t(const I8GemmArgs &g, dim3 grid, hipStream_t s) {
-    const size_t lds = ((I8_PIPE == 2 && BUF) ? 3 : 2) * (size_t)(TM + GQS * 32) * 64;
+    const size_t lds = 2 * (TM + GQS * 32) * 64;
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
@@ -2232,6 +2141,16 @@ static hipError_t launch_i8gemm_t(const I8GemmArgs &g, dim3 grid, hipStream_t s)
     return hipGetLastError();
 }
 
+// The 256-row tile also for the statistics product when it has >= 1024 rows (d >= 1024): its B operand -- the digit planes of wP,
+// 8 bytes per entry like the fp64 values they stand for -- is re-read once per row block, so half as many row blocks halve the
+// dominant operand traffic (config 4: 234.8 -> 222.6 ms).  PPCA_I8GEMM_S256=0: off.
+static bool i8gemm_s256() {
+    static const bool v = [] {
+        const char *e = getenv("PPCA_I8GEMM_S256");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
 static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     static const int tm = [] {  // PPCA_I8GEMM_TM=128: the 4-wave tile everywhere (A/B runs)
@@ -2246,20 +2165,29 @@ static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
     const bool buf = !nobuf && g.K % 64 == 0 && (g.ksplit % 64) == 0 && g.M * g.lda < (int64_t(1) << 31) &&
                      GQS * g.plane < (int64_t(1) << 31);
     hipError_t e;
-    // The 256-row tile also for the statistics product when it has >= 1024 rows (d >= 1024): its B operand -- the digit
-    // planes of wP, 8 bytes per entry like the fp64 values they stand for -- is re-read once per row block, so half
-    // as many row blocks halve the dominant operand traffic (config 4: 234.8 -> 222.6 ms).  PPCA_I8GEMM_S256=0: off.
-    static const bool s256 = [] {
-        const char *e = getenv("PPCA_I8GEMM_S256");
+    const bool s256 = i8gemm_s256();
+    // XCD-aware tile order (round 5; PPCA_I8GEMM_XCD=0: the plain 2-D order of rounds 1-4).  Measured at config 4's shape
+    // (profiles/r05/traffic_cfg4*.json): in the plain order the statistics product fetched its B stripes -- the digit planes of
+    // wP, 1.45 GB per chunk -- once per ROW BLOCK, because the four row blocks of a column block (linear ids x, x + 65, x + 130,
+    // x + 195) land on four different XCDs, i.e. four L2s: 190 KB of fabric traffic per sample and EM step in this kernel, 65 KB
+    // in the XCD-aware order (the whole pipeline: 304 -> 179 KB per sample).  The launch itself gains only 5 % (1.94 -> 1.84 ms: its
+    // K loop is not bound by that traffic); with fewer than two column blocks per XCD the order would idle XCDs
+    // (d = 512, k = 10, two column blocks: 12.4 against 8.8 ms per iteration), so it needs >= 16.
+    static const bool xcd = [] {
+        const char *e = getenv("PPCA_I8GEMM_XCD");
         return !(e && atoi(e) == 0);
     }();
-    if (tm == 256 && ((g.ksplit == 0 && g.M >= 4096) || (s256 && g.M >= 1024))) {  // tall products (the Gram: one row per sample): 256-row tile
-        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 255) / 256), g.ksplit > 0 ? (unsigned)g.nsplit : 1u);
-        e = buf ? launch_i8gemm_t<256, true>(g, grid, s) : launch_i8gemm_t<256, false>(g, grid, s);
-    } else {
-        dim3 grid((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 127) / 128), g.ksplit > 0 ? (unsigned)g.nsplit : 1u);
-        e = buf ? launch_i8gemm_t<128, true>(g, grid, s) : launch_i8gemm_t<128, false>(g, grid, s);
-    }
+    I8GemmArgs h = g;
+    const bool tall = tm == 256 && ((g.ksplit == 0 && g.M >= 4096) || (s256 && g.M >= 1024));  // (the Gram: one row per sample; S at d >= 1024)
+    const int tmr = tall ? 256 : 128;
+    h.ncb = (int)((g.N + 31) / 32);
+    h.nrb = (int)((g.M + tmr - 1) / tmr);
+    const int nz = g.ksplit > 0 ? g.nsplit : 1;
+    h.xcd_map = (xcd && h.ncb >= 16) ? 1 : 0;
+    dim3 grid((unsigned)h.ncb, (unsigned)h.nrb, (unsigned)nz);
+    if (h.xcd_map) grid = dim3((unsigned)(8 * ((h.ncb + 7) / 8) * h.nrb * nz), 1u, 1u);
+    if (tall) e = buf ? launch_i8gemm_t<256, true>(h, grid, s) : launch_i8gemm_t<256, false>(h, grid, s);
+    else e = buf ? launch_i8gemm_t<128, true>(h, grid, s) : launch_i8gemm_t<128, false>(h, grid, s);
     if (e != hipSuccess) return e;
     if (g.ksplit > 0) {
         const int64_t tot = g.M * g.N;
@@ -2527,12 +2455,39 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
                 q.A = W.AT; q.lda = W.npad; q.Bt = W.BtW; q.ldb = W.npad; q.plane = kp * W.npad;
                 q.M = d; q.N = kp; q.K = ncpad; q.scale = W.scaleW; q.out = stats + L.S; q.ldo = kp; q.accumulate = 1;
                 q.guard = W.flags + 1;
-                {   // two workgroups fit a CU: a grid a little above that many tiles runs a nearly empty second round
-                    const int64_t tiles = ((q.M + 127) / 128) * ((q.N + 31) / 32), slots = 2 * (int64_t)n_cu;
-                    if (tiles > slots && tiles < slots + slots / 2 && q.M * q.N <= W.part_cap && ncpad >= 256) {
-                        q.ksplit = (ncpad / 2 + 63) / 64 * 64;
-                        q.nsplit = 2;
-                        q.out2 = W.part;
+                bool launched = false;
+                {   // a grid a little above the tiles the chip runs at once spends a nearly empty extra round
+                    // (two 128-row workgroups fit a CU, one 256-row workgroup: launch_i8gemm picks the tile as below)
+                    const bool t256 = q.M >= 1024 && i8gemm_s256();
+                    const int64_t tmr = t256 ? 256 : 128, nrb = (q.M + tmr - 1) / tmr, ncb = (q.N + 31) / 32;
+                    const int64_t tiles = nrb * ncb, slots = (t256 ? 1 : 2) * (int64_t)n_cu;
+                    const int64_t cb_round = slots / nrb;                       // column blocks one full round of the chip takes
+                    const int64_t rest = cb_round > 0 ? ncb % cb_round : 0;     // ... and those left for a last, partly empty one
+                    if (tiles > slots && rest > 0 && rest * nrb * 4 <= slots && ncpad >= 8192) {
+                        // (round 5) config 4: 65 column blocks x 4 row blocks = 260 tiles on 256 CUs.  Rounds 3-4 cut K in two (520
+                        // workgroups: three rounds of half a tile, 1.5 tile times); now the 64 column blocks that fill the chip
+                        // exactly run whole, and the last one is cut along K into as many slices as fill it once more (64): 1.02
+                        // tile times.  Both launches go through the same kernel; the slices are added in slice order.
+                        I8GemmArgs q1 = q;
+                        q1.N = (ncb - rest) * 32;
+                        GTRY(launch_i8gemm(q1, s));
+                        I8GemmArgs q2 = q;
+                        const int64_t c0 = q1.N;
+                        q2.Bt = q.Bt + c0 * q.ldb;
+                        q2.scale = q.scale + c0;
+                        q2.out = q.out + c0;
+                        q2.N = q.N - c0;
+                        int64_t ns = slots / (rest * nrb);
+                        ns = std::min<int64_t>(ns, ncpad / 1024);                                         // >= 1024 samples per slice
+                        ns = std::min<int64_t>(ns, W.part_cap / std::max<int64_t>(1, q2.M * q2.N) + 1);  // partials that fit
+                        if (ns > 64) ns = 64;
+                        if (ns >= 2) {
+                            q2.ksplit = ((ncpad + ns - 1) / ns + 63) / 64 * 64;
+                            q2.nsplit = (int)((ncpad + q2.ksplit - 1) / q2.ksplit);
+                            q2.out2 = W.part;
+                        }
+                        GTRY(launch_i8gemm(q2, s));
+                        launched = true;
                     } else if (tiles < slots) {
                         // ... and a grid far below it leaves the chip idle: cut the samples into enough slices to fill it
                         int64_t ns = (slots + tiles - 1) / tiles;
@@ -2546,7 +2501,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
                         }
                     }
                 }
-                GTRY(launch_i8gemm(q, s));
+                if (!launched)                 GTRY(launch_i8gemm(q, s));
             }
             // S += Mask^T . wP (fp64 MFMA; with the int8 form enabled: only when the chunk's guard tripped)
             g.B = W.G; g.ldb = kp; g.M = d; g.N = kp; g.K = nc;
