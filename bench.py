@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # gfx950 correction calibrated on a known byte count): profiles/r01/README.md
 PMC_BYTES_PER_SAMPLE = 2077.5
 FP64_PEAK_TFLOPS = 78.6  # fp64 vector = fp64 matrix spec (dense MFMA peak for f64)
-TRAFFIC_FILES = ("profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
+TRAFFIC_FILES = ("profiles/r05/traffic.json", "profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
 
 
 def algorithmic_bytes_per_sample(d: int) -> float:
@@ -234,12 +234,15 @@ def traffic_from_profiles(rows_local: int):
 def sustained_mfma_from_profiles():
     """What a loop of nothing but independent MFMAs sustains on this part (tools/mfma_peak, run on the GPU box before the
     bench line; reported beside the guide's nominal peak, never instead of it)."""
-    try:
-        with open(os.path.join(ROOT, "profiles/r04/mfma_peak.json")) as fh:
-            pj = json.load(fh)
-        return pj
-    except (OSError, ValueError):
-        return None
+    for rel in ("profiles/r05/mfma_peak.json", "profiles/r04/mfma_peak.json"):
+        try:
+            with open(os.path.join(ROOT, rel)) as fh:
+                pj = json.load(fh)
+            pj["file"] = rel
+            return pj
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def main() -> None:
@@ -470,6 +473,17 @@ def main() -> None:
                            "finalisations (timed as one region" + (": ONE C-ABI call)" if em._one_call else ", composed from the C-ABI building blocks)"))
             kern_avg_ms, launches_rep = 1e3 * t_step, args.steps
             traffic, traffic_src = None, None
+            if (d, k, nm) == (256, 10, 8):
+                # HBM bytes per sample of ONE steady-state mixture iteration over every kernel it launches (tools/pmc_mix.py under
+                # separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes, tools/make_traffic_all.py), committed with its commit
+                try:
+                    with open(os.path.join(ROOT, "profiles/r05/traffic_cfg5.json")) as fh:
+                        tj = json.load(fh)
+                    traffic = tj["hbm_bytes_per_sample"] * rows_local
+                    traffic_src = (f"profiles/r05/traffic_cfg5.json (commit {tj.get('commit')}, {tj.get('n_samples')} rows x {tj.get('steps')} steady-state "
+                                   "mixture iterations, all kernels; fabric bytes, Infinity-Cache hits included)")
+                except (OSError, KeyError, ValueError):
+                    pass
         else:
             kern_avg_ms = kern_ms / max(launches, 1)
             launches_rep = launches
@@ -486,14 +500,16 @@ def main() -> None:
             if (d, k) == (1024, 64):
                 # config 4: HBM bytes per sample and EM step over EVERY kernel of the split pipeline (2 x FETCH_SIZE + WRITE_SIZE
                 # by separate rocprofv3 PMC passes of tools/pmc_generic.py), committed with the commit it was measured on
-                try:
-                    with open(os.path.join(ROOT, "profiles/r04/traffic_cfg4.json")) as fh:
-                        tj = json.load(fh)
-                    traffic = tj["hbm_bytes_per_sample"] * rows_local
-                    traffic_src = (f"profiles/r04/traffic_cfg4.json (commit {tj.get('commit')}, {tj.get('n_samples')} rows x {tj.get('em_steps')} EM steps, "
-                                   "all kernels of one pass; fabric bytes, Infinity-Cache hits included)")
-                except (OSError, KeyError, ValueError):
-                    pass
+                for rel in ("profiles/r05/traffic_cfg4.json", "profiles/r04/traffic_cfg4.json"):
+                    try:
+                        with open(os.path.join(ROOT, rel)) as fh:
+                            tj = json.load(fh)
+                        traffic = tj["hbm_bytes_per_sample"] * rows_local
+                        traffic_src = (f"{rel} (commit {tj.get('commit')}, {tj.get('n_samples')} rows x {tj.get('steps', tj.get('em_steps'))} EM steps, "
+                                       "all kernels of one pass; fabric bytes, Infinity-Cache hits included)")
+                        break
+                    except (OSError, KeyError, ValueError):
+                        continue
             if fused:
                 if eng.value == 1:
                     kernel_name = f"ppca::pass_kernel<{k}, true, 4, false, false>"  # the guard's fallback engine
@@ -543,7 +559,7 @@ def main() -> None:
             roofline["sustained_mfma"] = {
                 "fp64_tflops": sus["fp64_16x16x4_tflops_best"], "int8_pops": sus["int8_16x16x64_pops_best"],
                 "frac_of_sustained_fp64": tflops / sus["fp64_16x16x4_tflops_best"],
-                "source": "profiles/r04/mfma_peak.json (tools/mfma_peak: back-to-back independent MFMAs, no memory traffic; commit %s)" % sus.get("commit"),
+                "source": "%s (tools/mfma_peak: back-to-back independent MFMAs, no memory traffic; commit %s)" % (sus.get("file"), sus.get("commit")),
             }
         if mixture:
             roofline["note"] = ("frac = SURVEY.md 8(d)'s ONE-pass bytes (N x 2088 B: X read once per iteration) / step time / HBM peak; "

@@ -1055,6 +1055,196 @@ __global__ __launch_bounds__(128) void solve_kernel(SolveArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ state sizes 65 .. GENERIC_MAX_K (round 5): one WORKGROUP per matrix
+// The reference bounds the state size nowhere (ppca_model.rs:51-70, output_covariance.rs:57-70); rounds 1-4 refused k > 64 (a
+// wave's 64 lanes owned the rows of M).  A correct path without a performance claim: 256 threads, thread r < k owns row r of
+// M in LDS (k x (k | 1) doubles: 132 KB at k = 128), __syncthreads() where the wave forms have wave_sync().  The Cholesky
+// factor is inverted IN PLACE (row r of T = L^-1 from rows < r of T and row r of L), and M^-1 = T^T T is formed entry by entry
+// on the way out, so one matrix is all the LDS the solve needs.  Same I/O contract as solve_kernel.
+__device__ bool blk_cholesky(double *M, int k, int LD, int tid, double &logdet) {
+    bool ok = true;
+    double mant = 1.0;
+    int ex = 0;
+    __syncthreads();
+    for (int p = 0; p < k; ++p) {
+        const double piv = M[p * LD + p];
+        ok = ok && (piv > 0.0) && (piv < 1.0e308);
+        const double rinv = 1.0 / sqrt(piv);
+        int e;
+        mant *= frexp(piv, &e);
+        ex += e;
+        double lrp = 0.0;
+        __syncthreads();  // everyone has read the pivot before its slot is overwritten
+        if (tid > p && tid < k) {
+            lrp = M[tid * LD + p] * rinv;
+            M[tid * LD + p] = lrp;
+        }
+        if (tid == p) M[p * LD + p] = rinv;
+        __syncthreads();  // column p is final
+        if (tid > p && tid < k) {
+            double *myrow = M + tid * LD;
+            for (int c = p + 1; c <= tid; ++c) myrow[c] -= lrp * M[c * LD + p];
+        }
+        __syncthreads();  // trailing update visible before the next pivot is read
+    }
+    logdet = log(mant) + (double)ex * LN_2;
+    return ok;
+}
+// (L L^T) z = v with v, z in the LDS vector vs (thread r owns entry r); quad = |L^-1 v|^2 (red: 256 doubles of scratch)
+__device__ double blk_chol_solve(const double *M, int k, int LD, int tid, double *vs, double *red) {
+    for (int p = 0; p < k; ++p) {
+        __syncthreads();
+        const double yp = vs[p] * M[p * LD + p];
+        __syncthreads();
+        if (tid == p) vs[p] = yp;
+        if (tid > p && tid < k) vs[tid] -= M[tid * LD + p] * yp;
+    }
+    __syncthreads();
+    red[tid] = tid < k ? vs[tid] * vs[tid] : 0.0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const double quad = red[0];
+    for (int p = k - 1; p >= 0; --p) {
+        __syncthreads();
+        const double zp = vs[p] * M[p * LD + p];
+        __syncthreads();
+        if (tid == p) vs[p] = zp;
+        if (tid < p) vs[tid] -= M[p * LD + tid] * zp;
+    }
+    __syncthreads();
+    return quad;
+}
+// L (strict lower triangle, 1 / L_pp on the diagonal) -> T = L^-1 in place
+__device__ void blk_tri_inverse(double *M, int k, int LD, int tid) {
+    for (int r = 1; r < k; ++r) {
+        double v = 0.0;
+        if (tid < r) {
+            double s0 = 0.0;
+            for (int t = tid; t < r; ++t) s0 += M[r * LD + t] * (t == tid ? M[t * LD + t] : M[t * LD + tid]);
+            v = -s0 * M[r * LD + r];
+        }
+        __syncthreads();  // everyone has read row r of L
+        if (tid < r) M[r * LD + tid] = v;
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ double blk_sum(double v, double *red, int tid) {
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    return red[0];
+}
+__global__ __launch_bounds__(256) void solve_big_kernel(SolveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int tid = threadIdx.x;
+    const int k = a.k, kp = k * (k + 1) / 2, LD = k | 1;
+    double *M = gsm, *vs = M + (size_t)k * LD, *zs = vs + k, *red = zs + k;
+    const double s2 = a.model[1], lnsig = a.model[2];
+    for (int64_t i = blockIdx.x; i < a.n; i += gridDim.x) {
+        double *g = a.G + i * kp;
+        double *bz = a.Bz + i * (k + 1);
+        __syncthreads();  // the previous sample's reads of M / vs / zs are done
+        for (int r = tid; r < k; r += 256)
+            for (int c = 0; c <= r; ++c) M[r * LD + c] = g[r * (r + 1) / 2 + c] + (r == c ? s2 : 0.0);
+        if (tid < k) vs[tid] = bz[tid];
+        double logdet;
+        blk_cholesky(M, k, LD, tid, logdet);
+        const double quad = blk_chol_solve(M, k, LD, tid, vs, red);
+        const double z = tid < k ? vs[tid] : 0.0;
+        if (tid < k) zs[tid] = z;
+        const double zz = blk_sum(z * z, red, tid);
+        blk_tri_inverse(M, k, LD, tid);
+        // (M^-1)_rc = sum_{t >= r} T_tr T_tc for r >= c; the diagonal first, for the trace
+        double trp = 0.0;
+        if (tid < k) {
+            double s0 = 0.0;
+            for (int t = tid; t < k; ++t) s0 += M[t * LD + tid] * M[t * LD + tid];
+            trp = s0;
+        }
+        const double tr = blk_sum(trp, red, tid);
+        const double wgt = a.w ? a.w[i] : 1.0;
+        const double xx = a.xx[i];
+        const int m = (int)a.mc[i];
+        const double lk = sample_llk(xx, quad, logdet, s2, lnsig, m, k);
+        for (int e = tid; e < kp; e += 256) {
+            int r = 0;
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            const int c = e - r * (r + 1) / 2;
+            double s0 = 0.0;
+            for (int t = r; t < k; ++t) s0 += M[t * LD + r] * M[t * LD + c];
+            if (a.em) {
+                g[e] = wgt * (zs[r] * zs[c] + s2 * s0);  // w P = w (z z^T + s2 M^-1), packed
+            } else {
+                const double sv = s2 * s0;
+                g[e] = sv;  // Sigma packed, for the covariance diagonals
+                if (a.covs) {
+                    a.covs[(i * k + r) * k + c] = sv;
+                    a.covs[(i * k + c) * k + r] = sv;
+                }
+            }
+        }
+        if (tid < k) {
+            bz[tid] = a.em ? wgt * z : z;
+            if (!a.em && a.states) a.states[i * k + tid] = z;
+        }
+        if (tid == 0) {
+            double *sc = a.sc + i * 4;
+            if (a.em) {
+                bz[k] = wgt;
+                sc[0] = m > 0 ? wgt * s2 * ((double)k - s2 * tr) : 0.0;
+                sc[1] = m > 0 ? wgt * (xx - quad - s2 * zz) : 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = m > 0 ? 1.0 : 0.0;
+            } else {
+                sc[0] = 0.0;
+                sc[1] = 0.0;
+                sc[2] = wgt * lk;
+                sc[3] = 0.0;
+                if (a.llks) a.llks[i] = lk;
+            }
+        }
+    }
+}
+static size_t solve_big_lds(int k) { return sizeof(double) * ((size_t)k * (k | 1) + 2 * (size_t)k + 256); }
+static hipError_t launch_solve_big(const SolveArgs &a, int n_cu, hipStream_t s) {
+    const size_t lds = solve_big_lds(a.k);
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e != hipSuccess)
+        return e;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.n, (int64_t)n_cu));
+    hipLaunchKernelGGL(solve_big_kernel, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+// finalisation's row systems at k > 64: one workgroup per dimension
+__global__ __launch_bounds__(256) void gen_rowsolve_big_kernel(const double *stats, const double *min, double *mout, int d, int k, double tau) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int tid = threadIdx.x;
+    const int kp = k * (k + 1) / 2, LD = k | 1;
+    double *M = gsm, *vs = M + (size_t)k * LD, *red = vs + 2 * k;
+    const StatsLayout L(d, k);
+    for (int j = blockIdx.x; j < d; j += gridDim.x) {
+        const double *S = stats + L.S + (int64_t)j * kp;
+        __syncthreads();
+        for (int r = tid; r < k; r += 256)
+            for (int c = 0; c <= r; ++c) M[r * LD + c] = S[r * (r + 1) / 2 + c] + (r == c ? tau : 0.0);
+        if (tid < k) vs[tid] = stats[L.cross + (int64_t)j * k + tid];
+        double logdet;
+        const bool ok = blk_cholesky(M, k, LD, tid, logdet);
+        (void)blk_chol_solve(M, k, LD, tid, vs, red);
+        if (tid < k) {
+            const double old = min[MODEL_HDR + (int64_t)j * k + tid];
+            mout[MODEL_HDR + (int64_t)j * k + tid] = ok ? vs[tid] : old;  // :313-321 keep the old row
+        }
+    }
+}
+
 // ------------------------------------------------------------------ per-sample solve, one LANE per sample (k <= 16)
 // The blocked / broadcast solvers below give a whole wave to one sample: right at k = 64, a 70-fold waste at k = 11
 // (13 k cycles per sample and wave: 6.4 ms of a 16 ms chunk one step outside the fused kernel).  Up to k = 16 the
@@ -1771,6 +1961,7 @@ static hipError_t launch_solve_mfma(const SolveArgs &a, int n_cu, hipStream_t s)
     return hipGetLastError();
 }
 static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
+    if (a.k > 64) return launch_solve_big(a, n_cu, s);
     int grid = (int)std::min<int64_t>((a.n + 3) / 4, (int64_t)n_cu);
     if (grid < 1) grid = 1;
     static const bool reg = [] {  // PPCA_GENERIC_REG_SOLVE=1: the v_readlane-broadcast form (A/B runs)
@@ -2360,7 +2551,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
     GenWs W = carve(ws, d, k, n);
     const double *mean = model + MODEL_HDR + (int64_t)d * k;
     const double *Cm = model + MODEL_HDR;
-    const bool i8 = generic_i8();
+    const bool i8 = generic_i8() && k <= 64;  // (k > 64: the fp64 contractions and the workgroup-per-matrix solver, no performance claim)
     if (em && i8 && em16_enabled() && em16_covers(d, k)) return run_em16(X, ldx, w, n, d, k, model, stats, W, n_cu, s);
     {
         const int64_t tot = (int64_t)d * kp;
@@ -2373,7 +2564,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
             GTRY(hipGetLastError());
         }
     }
-    GTRY(set_solve_lds(k));
+    if (k <= 64) GTRY(set_solve_lds(k));
     if (em) GTRY(hipMemsetAsync(stats, 0, sizeof(double) * (size_t)L.len, s));
     for (int64_t r0 = 0; r0 < n; r0 += W.chunk) {
         const int64_t nc = std::min(W.chunk, n - r0);
@@ -2382,7 +2573,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         GemmArgs g{};
         g.X = Xc; g.ldx = ldx; g.mean = mean;
         const int64_t ncpad = pad64(nc);
-        const bool prep = prep_enabled();
+        const bool prep = prep_enabled() && k <= 64;
         if (prep) {  // row statistics, mask bytes and b = X~ C in one pass over the chunk's rows
             const dim3 pg((unsigned)(ncpad / 64));
             if (k <= 16) hipLaunchKernelGGL((gen_prep_kernel<1>), pg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
@@ -2526,7 +2717,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
                 const char *e = getenv("PPCA_GENERIC_RECON");
                 return e && e[0] == 'n';
             }();
-            if (naive) {
+            if (naive || k > 64) {
                 const int64_t tot = nc * d;
                 hipLaunchKernelGGL(recon_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Xc, ldx, nc, d, k,
                                    model, W.Bz, W.G, recon_mode, recon + r0 * d);
@@ -2548,7 +2739,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
 // otherwise -1 and *flag_dev points at the guard flag (0 = int8-sliced, non-zero = fp64) the digit kernels just wrote.
 // ws: a workspace of generic_workspace_bytes(d, k, 1).
 hipError_t generic_gram_guard(int d, int k, const double *model, void *ws, hipStream_t s, const int **flag_dev, int *forced) {
-    if (!generic_i8()) {
+    if (!generic_i8() || k > 64) {
         *forced = 1;
         return hipSuccess;
     }
@@ -2586,6 +2777,14 @@ hipError_t generic_post(const double *X, int64_t ldx, const double *w, int64_t n
 
 hipError_t generic_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
                             int has_ig, double alpha, double beta, int n_cu, hipStream_t s) {
+    if (k > 64) {  // one workgroup per dimension (solve_big_kernel's tools)
+        const size_t lds = solve_big_lds(k);
+        GTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&gen_rowsolve_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gen_rowsolve_big_kernel, dim3((unsigned)std::min(d, 4 * n_cu)), dim3(256), lds, s, stats, model_in, model_out, d, k, tau);
+        GTRY(hipGetLastError());
+        hipLaunchKernelGGL(gen_finalize_misc_kernel, dim3(1), dim3(256), 0, s, stats, model_in, model_out, d, k, has_ig, alpha, beta);
+        return hipGetLastError();
+    }
     const size_t lds = sizeof(double) * 2 * (size_t)(k * (k | 1) + 64);
     static size_t cur = 0;
     if (lds > cur) {

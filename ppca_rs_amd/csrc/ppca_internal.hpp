@@ -172,8 +172,9 @@ hipError_t launch_scale_rows(double *X, int64_t ldx, int d, const int64_t *rows_
 hipError_t launch_mfma_i8_probe(const int *a, const int *b, int *out, hipStream_t s);
 hipError_t launch_mfma_probe(const double *a16x4, const double *b4x16, double *out16x16, hipStream_t s);
 
-// generic split pipeline (ppca_generic.hip): any d, k <= GENERIC_MAX_K
-constexpr int GENERIC_MAX_K = 64;
+// generic split pipeline (ppca_generic.hip): any d, k <= GENERIC_MAX_K (k <= 64 on the tuned kernels; 65..128 on fp64 contractions and a
+// workgroup-per-matrix solver whose k x k matrix is what 160 KB of LDS hold: correct, no performance claim)
+constexpr int GENERIC_MAX_K = 128;
 size_t generic_workspace_bytes(int d, int k, int64_t n);
 hipError_t generic_em_accumulate(const double *X, int64_t ldx, const double *w, int64_t n, int d, int k,
                                  const double *model, double *stats, void *ws, int n_cu, hipStream_t s);

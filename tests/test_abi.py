@@ -31,7 +31,8 @@ def test_path_kind_and_stats_len(hiplib):
     assert hiplib.ppca_path_kind(32, 4) == 1
     assert hiplib.ppca_path_kind(0, 4) < 0
     assert hiplib.ppca_path_kind(1024, 64) == 0 and hiplib.ppca_path_kind(300, 4) == 0
-    assert hiplib.ppca_path_kind(32, 65) < 0
+    assert hiplib.ppca_path_kind(32, 65) == 0 and hiplib.ppca_path_kind(32, 128) == 0  # (round 5: the slow correct path up to k = 128)
+    assert hiplib.ppca_path_kind(32, 129) < 0
     d, k = 256, 10
     assert hiplib.ppca_stats_len(d, k) == 2 * d * k + d * 55 + 2 * d + 8
 

@@ -638,7 +638,11 @@ def test_full_size_properties(P):
                                             (257, 1024, 64, 0.5, True), (90, 40, 12, 0.4, False),
                                             (300, 70, 20, 0.3, False), (200, 513, 10, 0.3, False),
                                             (301, 80, 40, 0.3, False), (203, 64, 32, 0.3, False), (7, 40, 17, 0.2, False),
-                                            (130, 70, 48, 0.2, False), (66, 90, 49, 0.1, False)])
+                                            (130, 70, 48, 0.2, False), (66, 90, 49, 0.1, False),
+                                            # state sizes beyond 64 (round 5; the reference bounds k nowhere, ppca_model.rs:51-70): fp64
+                                            # contractions + the workgroup-per-matrix solver of ppca_generic.hip, up to the 128 x 128
+                                            # matrix that 160 KB of LDS hold
+                                            (150, 90, 65, 0.2, False), (120, 140, 100, 0.3, False), (70, 150, 128, 0.2, False)])
 def test_generic_pipeline_matches_oracle(P, oracle, n, d, k, mp, block):
     """Shapes outside the fused kernel (d > 256 or k > 10) run the split pipeline
     (ppca_generic.hip); BASELINE config 4 (d = 1024, k = 64, 50 % block-masked) at oracle-sized N."""

@@ -34,12 +34,13 @@ def main():
     use = lambda k: not any(s in k for s in SKIP)
     ft, wt = sum(v for k, v in f if use(k)), sum(v for k, v in w if use(k))
     per_kernel = {}
+    short = lambda k: k.replace("(anonymous namespace)::", "").split("(")[0][:80]
     for k, v in f:
         if use(k):
-            per_kernel[k.split("(")[0][:80]] = per_kernel.get(k.split("(")[0][:80], 0.0) + ratio * v * 1024
+            per_kernel[short(k)] = per_kernel.get(short(k), 0.0) + ratio * v * 1024
     for k, v in w:
         if use(k):
-            per_kernel[k.split("(")[0][:80]] = per_kernel.get(k.split("(")[0][:80], 0.0) + v * 1024
+            per_kernel[short(k)] = per_kernel.get(short(k), 0.0) + v * 1024
     total = ratio * ft * 1024 + wt * 1024
     top = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:8]
     j = {"commit": commit, "what": what, "n_samples": n, "steps": steps, "FETCH_SIZE_KB_total": ft, "WRITE_SIZE_KB_total": wt,
