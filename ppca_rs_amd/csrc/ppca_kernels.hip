@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *part
 // finalises redundantly, then builds its tile of the new model's slice table from there).
 template <int K>
 __device__ __forceinline__ void finalize_body(const double *stats, const double *min, double *mout, int d, double tau, int has_ig,
-                                              double alpha, double beta, bool write, double *cn_lds, double *s2_lds, double *stage) {
+                                              double alpha, double beta, bool write, double *cn_lds, double *s2_lds) {
     constexpr int KP = K * (K + 1) / 2;
     StatsLayout L(d, K);
     __shared__ double red[256];
@@ -1611,53 +1611,29 @@ __device__ __forceinline__ void finalize_body(const double *stats, const double 
     const double *Mold = Cold + (int64_t)d * K;
     double *Cnew = mout + MODEL_HDR;
     double *Mnew = Cnew + (int64_t)d * K;
-    // (round 5) The d row systems are one per thread, but thread j reading ITS 55 + 30 doubles straight from global memory is 85
-    // load instructions that each touch 64 different cache lines -- 9 of this kernel's ~9 us at one CU's 64 lanes per clock.
-    // The block copies S, then [cross | U | old C], into LDS with whole-line loads; a thread takes its row from there (odd row
-    // stride of S: conflict-free), and the new transform leaves through LDS the same way.  d <= 256 (the fused path).
-    {
-        const int j = tid;
+    for (int j = tid; j < d; j += 256) {
         double S[KP], rhs[K], cn[K];
-        for (int idx = tid; idx < d * KP; idx += 256) stage[idx] = stats[L.S + idx];
-        __syncthreads();
-        if (j < d) {
 #pragma unroll
-            for (int e = 0; e < KP; ++e) S[e] = stage[j * KP + e];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < d * K; idx += 256) {
-            stage[idx] = stats[L.cross + idx];
-            stage[d * K + idx] = stats[L.U + idx];
-            stage[2 * d * K + idx] = Cold[idx];
-        }
-        __syncthreads();
+        for (int e = 0; e < KP; ++e) S[e] = stats[L.S + (int64_t)j * KP + e];
         double cz = 0.0;
-        if (j < d) {
 #pragma unroll
-            for (int a = 0; a < K; ++a) {
-                rhs[a] = stage[j * K + a];
-                cn[a] = stage[2 * d * K + j * K + a];  // keep the old row if the system is singular (:313-321)
-                cz += cn[a] * stage[d * K + j * K + a];
-            }
-            row_solve<K>(S, tau, rhs, cn);
+        for (int a = 0; a < K; ++a) {
+            rhs[a] = stats[L.cross + (int64_t)j * K + a];
+            cn[a] = Cold[(int64_t)j * K + a];  // keep the old row if the system is singular (:313-321)
+            cz += cn[a] * stats[L.U + (int64_t)j * K + a];
         }
-        __syncthreads();
-        if (j < d) {
+        row_solve<K>(S, tau, rhs, cn);
+        if (cn_lds) {
 #pragma unroll
-            for (int a = 0; a < K; ++a) stage[j * K + a] = cn[a];
-            if (cn_lds) {
-#pragma unroll
-                for (int a = 0; a < K; ++a) cn_lds[j * K + a] = cn[a];
-            }
-            if (write) {
-                const double tot = stats[L.totals + j];
-                const double totdev = stats[L.sumx + j] - cz;  // sum_i w_i m_ij (x_ij - c_j.z_i - mu_j)  (:338-347)
-                Mnew[j] = (tot > 0.0 ? totdev / tot : 0.0) + Mold[j];  // :373-377
-            }
+            for (int a = 0; a < K; ++a) cn_lds[j * K + a] = cn[a];
         }
-        __syncthreads();
-        if (write)
-            for (int idx = tid; idx < d * K; idx += 256) Cnew[idx] = stage[idx];
+        if (write) {
+#pragma unroll
+            for (int a = 0; a < K; ++a) Cnew[(int64_t)j * K + a] = cn[a];
+            const double tot = stats[L.totals + j];
+            const double totdev = stats[L.sumx + j] - cz;  // sum_i w_i m_ij (x_ij - c_j.z_i - mu_j)  (:338-347)
+            Mnew[j] = (tot > 0.0 ? totdev / tot : 0.0) + Mold[j];  // :373-377
+        }
     }
     const double sig = sqrt(s2new);  // :389
     if (tid == 0) {
@@ -1673,8 +1649,7 @@ __device__ __forceinline__ void finalize_body(const double *stats, const double 
 template <int K>
 __global__ __launch_bounds__(256) void finalize_kernel(const double *stats, const double *min, double *mout, int d,
                                                        double tau, int has_ig, double alpha, double beta) {
-    extern __shared__ __attribute__((aligned(16))) double fin_stage[];  // FUSED_MAX_D x K' doubles (launch_finalize)
-    finalize_body<K>(stats, min, mout, d, tau, has_ig, alpha, beta, true, nullptr, nullptr, fin_stage);
+    finalize_body<K>(stats, min, mout, d, tau, has_ig, alpha, beta, true, nullptr, nullptr);
 }
 // The plain EM step's finalisation AND the next pass's qprep_kernel in one launch: grid = the packed-column tiles of the slice
 // table; every workgroup finalises (d row systems, one per thread: redundant and concurrent), workgroup 0 stores the model, then
@@ -1685,8 +1660,7 @@ __global__ __launch_bounds__(256) void finalize_qprep_kernel(const double *stats
                                                              int *qflag) {
     __shared__ double cn[FUSED_MAX_D * K];
     __shared__ double s2n;
-    extern __shared__ __attribute__((aligned(16))) double fin_stage[];  // FUSED_MAX_D x K' doubles (launch_finalize_qprep)
-    finalize_body<K>(stats, min, mout, d, tau, has_ig, alpha, beta, blockIdx.x == 0, cn, &s2n, fin_stage);
+    finalize_body<K>(stats, min, mout, d, tau, has_ig, alpha, beta, blockIdx.x == 0, cn, &s2n);
     __syncthreads();
     qprep_body<K>([&](int j, int a) { return cn[j * K + a]; }, s2n, d, qscale, qtab, qflag);
 }
@@ -2154,33 +2128,17 @@ hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t le
     return hipGetLastError();
 }
 
-// dynamic LDS of the two finalisation kernels: S of all dimensions (the largest of the three things staged there)
-template <int K>
-static size_t finalize_lds() {
-    constexpr int KP = K * (K + 1) / 2;
-    return sizeof(double) * FUSED_MAX_D * (KP > 3 * K ? KP : 3 * K);
-}
-template <class KernelT>
-static hipError_t big_lds(KernelT kernel, size_t lds) {  // (> 64 KB of dynamic LDS needs the attribute once per device)
-    if (lds <= 65536) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
 hipError_t launch_finalize(int k, int d, const double *stats, const double *model_in, double *model_out, double tau,
                            int has_ig, double alpha, double beta, hipStream_t s) {
-    PPCA_DISPATCH_K(k, {
-        if (hipError_t e = big_lds(&finalize_kernel<KK>, finalize_lds<KK>()); e != hipSuccess) return e;
-        hipLaunchKernelGGL((finalize_kernel<KK>), dim3(1), dim3(256), finalize_lds<KK>(), s, stats, model_in, model_out, d, tau, has_ig, alpha, beta);
-    });
+    PPCA_DISPATCH_K(k, hipLaunchKernelGGL((finalize_kernel<KK>), dim3(1), dim3(256), 0, s, stats, model_in, model_out,
+                                          d, tau, has_ig, alpha, beta));
     return hipGetLastError();
 }
 
 hipError_t launch_finalize_qprep(int k, int d, const double *stats, const double *model_in, double *model_out, double tau, int has_ig,
                                  double alpha, double beta, const PassArgs &tab, hipStream_t s) {
-    PPCA_DISPATCH_K(k, {
-        if (hipError_t e = big_lds(&finalize_qprep_kernel<KK>, finalize_lds<KK>()); e != hipSuccess) return e;
-        hipLaunchKernelGGL((finalize_qprep_kernel<KK>), dim3(Cfg<KK>::NTP), dim3(256), finalize_lds<KK>(), s, stats, model_in, model_out, d, tau,
-                           has_ig, alpha, beta, tab.qscale, tab.qtab, tab.qflag);
-    });
+    PPCA_DISPATCH_K(k, hipLaunchKernelGGL((finalize_qprep_kernel<KK>), dim3(Cfg<KK>::NTP), dim3(256), 0, s, stats, model_in, model_out, d,
+                                          tau, has_ig, alpha, beta, tab.qscale, tab.qtab, tab.qflag));
     return hipGetLastError();
 }
 

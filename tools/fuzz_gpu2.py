@@ -1,5 +1,5 @@
 """Randomised parity sweep aimed at the fixed-point statistics (round 4): outlier rows, heavy-tailed weights, capped grids
-(a workgroup walks many tiles), every engine (eight-wave kernel k <= 10, two-kernel pass k = 11..16, split pipeline) --
+(a workgroup walks many tiles), copies of one row (correlated roundings: round 5), every engine (eight-wave kernel k <= 10, two-kernel pass k = 11..16, split pipeline) --
 the statistics against the oracle block by block AND, for the diagonal of S and the totals, DIMENSION BY DIMENSION
 (element-wise relative), which is what an outlier row breaks when the guard is missing.  Diagnostic; run on the GPU box:
 
@@ -33,8 +33,20 @@ def one_case(case):
     n = int(rng.integers(200, 3000))
     x = rng.standard_normal((n, k)) @ rng.standard_normal((k, d)) + 0.1 * rng.standard_normal((n, d)) + rng.standard_normal(d)
     x[rng.random((n, d)) < rng.uniform(0.05, 0.6)] = np.nan
-    flavour = int(rng.integers(0, 4))
+    flavour = int(rng.integers(0, 6))
     w = None
+    if flavour in (4, 5):
+        # CORRELATED roundings (round 5): most rows are copies of ONE row (same values, same mask), so the cut of their [wP | wz | w]
+        # rows rounds every copy the same way -- the guard's bound counts 4 sqrt(rows) quanta per flush window as if the roundings were
+        # independent; with copies the error of a column sum grows like rows x quantum / 2.  An outlier row among them lifts the
+        # exponents (flavour 5: and masks some dimensions), which is where coarse cuts + correlated roundings could add up.
+        src = int(rng.integers(0, n))
+        copies = rng.random(n) < 0.9
+        x[copies] = x[src]
+        big = int(rng.integers(0, n))
+        x[big] = rng.standard_normal(d) * 10.0 ** rng.uniform(3, 7)
+        if flavour == 5:
+            x[big, rng.random(d) < 0.5] = np.nan
     if flavour in (1, 3):  # outlier rows
         for i in rng.choice(n, size=int(rng.integers(1, 4)), replace=False):
             x[i] *= 10.0 ** rng.uniform(2, 8)
