@@ -40,15 +40,25 @@ constexpr int E9_FLUSH_GROUPS = 100;
 #ifndef E9_FRONT_PRIO
 #define E9_FRONT_PRIO 0
 #endif
+#ifndef E9_CLDS
+#define E9_CLDS 0  // 1 (round 5, "layout B"): b = X~ C on the 4 x 4 x 4 form with the first two column groups of C RESIDENT IN LDS (16 KB; the third
+                   // from L1 / L2), the LDS for it reclaimed at k = 10 from: digit planes packed to their real columns (6.1 KB), the second K-half
+                   // partial of b in the row's free slots instead of its own array (2.8), the row stride 82 -> 78 (2), the mean re-read from L1 / L2
+                   // instead of an LDS copy (2), the per-lane running sum of tr(C Sigma C^T) in a register instead of LDS (2)
+#endif
 #ifndef E9_B444
-#define E9_B444 0  // 1: b = X~ C on v_mfma_f64_4x4x4 with the dimension and sample groups in the instruction's four blocks (round 5
+#define E9_B444 E9_CLDS
+#endif
+#if E9_CLDS && !E9_B444
+#error "E9_CLDS is the 4 x 4 x 4 form of the b product"
+#endif
+// E9_B444 alone (C operands from L1 / L2): b = X~ C on v_mfma_f64_4x4x4 with the dimension and sample groups in the instruction's four blocks (round 5
                    // experiment, parity-green).  Measured (gpurun_out/r5ab1, r5ab2, r5t1, r5t2; profiles/r05/README.md): 100.0 against
                    // 100.7 EM it/s for the 16 x 16 x 4 form -- the loop's 96 MFMAs of 17 cycles take 2.84 k cycles per tile against
                    // 2.70 k for 32 of 64: the 48 loads of C per wave and tile queue behind the Gram's digit-table loads (one in-order
                    // vmcnt), deeper look-ahead changes nothing (E9_LAC=6: 99.9).  With the C operands from LDS (timing experiment
                    // E9_EXP_CLDS, results wrong) the loop takes 2.22 k and the launch 104.8 it/s -- but LDS has 1.7 KB free where 20 KB are
-                   // needed, and what can be reclaimed (66-column digit planes 6.3, mean 2, row stride 2, second b partial 2.8) stops at 15.
-#endif
+                   // needed: E9_CLDS reclaims 16 for two of the three column groups.
 #if E9_B444 && !defined(PPCA_WITH_CPB)
 #error "E9_B444=1 reads PassArgs::cpb: build ppca_kernels.hip with -DPPCA_WITH_CPB as well (tools/devbuild.py passes -D flags to both)"
 #endif
@@ -68,6 +78,9 @@ constexpr int E9_FLUSH_GROUPS = 100;
 #ifndef E9_QB_EARLY
 #define E9_QB_EARLY 0  // 1: the second digit pair {5,4} requested with {7,6} during the previous tile's P4a (round 5 experiment): the
                        // first half of the Gram 2.40 -> 2.12 k cycles per tile, the b loop 2.70 -> 2.87 k, the launch 100.7 against 100.8 it/s
+#endif
+#ifndef E9_PLANES_PACKED
+#define E9_PLANES_PACKED 1
 #endif
 #ifndef E9_GS_PAD
 #define E9_GS_PAD 18  // row stride of [G | b] / W rows = 16 NTP + 18 doubles: even, so that the solver's lane-per-sample accesses
@@ -96,10 +109,18 @@ struct Cfg9 {
     //   as [G | b]:      G (16 NTP, K' used)        | b partial of dims 0-127 (16)          | pad (2)
     //   after the solve: L (K')  .. z in free slots | w z (K) | w | z in free slots ..      | z
     //   as W row:        w P (K') ..                | w z (K) | w | ..
-    static constexpr int GS = 16 * NTP + E9_GS_PAD;
+    static constexpr bool CLDS = E9_CLDS != 0;
+    static constexpr int NCGB = (K + 3) / 4;                          // column groups of four of b = X~ C (4 x 4 x 4 form)
+    static constexpr int NCL = CLDS ? (NCGB < 2 ? NCGB : 2) : 0;      // ... whose C operands are resident in LDS
+    static constexpr int PADC = (CLDS && K == 10) ? 14 : E9_GS_PAD;   // width of the row's b area + pad (layout B squeezes k = 10)
+    static constexpr int GS = 16 * NTP + PADC;
     static constexpr int WS = GS;
-    static constexpr int BS = K + 1;             // b partial of dims 128-255
-    static constexpr int PLANE_BYTES = E9_QW * 2 * NCOL * 16;  // digit planes of one tile: [plane][16-sample chunk][column][16 B]
+    static constexpr int BS = CLDS ? 0 : K + 1;  // b partial of dims 128-255 (layout B: in the row's free slots, p1slot below)
+    // digit planes of one tile: [plane][16-sample chunk][column][16 B].  (round 5) NCP = the NC real columns, not the NCOL of the 16-column
+    // tiles: the lanes of the last column tile that stand for columns >= NC read whatever follows (the next chunk row, or the words
+    // behind the region): their digit sums are never emitted (emit: c < NC) -- 14 columns x 14 rows x 16 B x 2 regions = 6.1 KB of LDS.
+    static constexpr int NCP = E9_PLANES_PACKED ? NC : NCOL;
+    static constexpr int PLANE_BYTES = E9_QW * 2 * NCP * 16;
     static constexpr int OFF_X = 0;
     static constexpr int OFF_G = OFF_X + B * XS;          // two buffers: tile parity
     static constexpr int OFF_W = OFF_G;
@@ -108,15 +129,20 @@ struct Cfg9 {
     static constexpr int OFF_MB = OFF_M + 2 * B * 4;      // sample masks per dimension: DP x 4 u32 (slot = tile % 4)
     static constexpr int OFF_S = OFF_MB + DP * 2;         // cross-wave scratch
     static constexpr int OFF_L = OFF_S + 2 * B;           // running scalars: sq[4][2 B] | dev | llk | w | ne | pm | px
-    static constexpr int OFF_P0 = OFF_L + 14 * B;         // digit planes of a group's first tile
+    static constexpr int OFF_P0 = OFF_L + (CLDS ? 6 : 14) * B;  // digit planes of a group's first tile (layout B: sq lives in a register)
     static constexpr int OFF_P1 = OFF_P0 + PLANE_BYTES / 8;  // ... and of its second
     static constexpr int OFF_E = OFF_P1 + PLANE_BYTES / 8;  // column exponents (NCOL ints), flags
     static constexpr int OFF_BAR = OFF_E + NCOL / 2 + 4;  // counters: front barrier, back barrier, tiles digitised, violation stamp
     static constexpr int OFF_MU = OFF_BAR + 4;  // the mean (DP doubles, zero past d): re-read by the staging of every tile
-    static constexpr int OFF_K = OFF_MU + DP;             // model scalars: sigma^2, 1 / sigma^2, ln sigma (re-read per tile)
+    static constexpr int OFF_K = OFF_MU + (CLDS ? 0 : DP);  // model scalars: sigma^2, 1 / sigma^2, ln sigma (re-read per tile)
     static constexpr int OFF_EB = OFF_K + 4;              // rounding bounds of the cut, per column (wguard_kernel)
     static constexpr int OFF_XT = OFF_EB + NCOL;          // by-products of the solve (quad, |z|^2, det M) per sample, two tile parities
-    static constexpr int LDS_DOUBLES = OFF_XT + 2 * B * 4;
+    static constexpr int OFF_CL = OFF_XT + 2 * B * 4;     // (layout B) C^T operands of the first NCL column groups: [K-half][step][group][32]
+    static constexpr int LDS_DOUBLES = OFF_CL + 2 * 16 * NCL * 32;
+    // where the second K-half's partial of b[a] waits for the solver (layout B): the row's free slots at that time -- what is left of
+    // the b area behind the K columns of the first half, then the G part's unused packed columns
+    static constexpr int p1slot(int a) { return a < PADC - K ? 16 * NTP + K + a : KP + (a - (PADC - K)); }
+    static_assert(!CLDS || K - (PADC - K) <= 16 * NTP - KP, "free slots of a row hold the second partial of b");
     static_assert(NCOL / 2 <= 64, "one back wave digitises NCOL / 2 (column, chunk) items");
     static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget");
 };
@@ -154,7 +180,7 @@ template <int K, bool GATHER, bool WEIGHTED>
 __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     using cfg = Cfg9<K>;
     constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS, BS = cfg::BS,
-                  WS = cfg::WS, NC = cfg::NC, NCT = cfg::NCT, NCOL = cfg::NCOL;
+                  WS = cfg::WS, NC = cfg::NC, NCT = cfg::NCT, NCOL = cfg::NCOL, NCP = cfg::NCP;
     constexpr int NF = 4;              // waves per role
     constexpr int RPW = B / NF;        // rows staged per front wave
     constexpr int DPS = cfg::DP / 2;   // dims per K-split of b = X~ C
@@ -195,12 +221,21 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 
     constexpr bool PAIRS = K >= 2;
     constexpr int SQW = PAIRS ? 2 * B : B;  // sq slots per front wave
-    constexpr int L_DEV = NF * SQW, L_LLK = L_DEV + B, L_W = L_DEV + 2 * B, L_NE = L_DEV + 3 * B, L_PM = L_DEV + 4 * B,
+    constexpr bool CLDS = cfg::CLDS;
+    constexpr int L_DEV = CLDS ? 0 : NF * SQW, L_LLK = L_DEV + B, L_W = L_DEV + 2 * B, L_NE = L_DEV + 3 * B, L_PM = L_DEV + 4 * B,
                   L_PX = L_DEV + 5 * B;
-    static_assert(L_DEV + 6 * B <= 14 * B, "scalar slots");
+    static_assert(L_DEV + 6 * B <= (CLDS ? 6 : 14) * B, "scalar slots");
     for (int idx = tid; idx < L_DEV + 6 * B; idx += 512) scl[idx] = (idx >= L_PM && idx < L_PX) ? 1.0 : 0.0;
     for (int idx = tid; idx < cfg::DP * 4; idx += 512) Mb[idx] = 0u;
-    for (int idx = tid; idx < cfg::DP; idx += 512) sm[cfg::OFF_MU + idx] = idx < d ? mMean[idx] : 0.0;
+    if constexpr (!CLDS) {
+        for (int idx = tid; idx < cfg::DP; idx += 512) sm[cfg::OFF_MU + idx] = idx < d ? mMean[idx] : 0.0;
+    } else {  // the resident part of C^T in operand order: [K-half][step][group < NCL][32] of PassArgs::cpb's [..][group < NCGB][32]
+        constexpr int NCL = cfg::NCL, NCGB = cfg::NCGB;
+        for (int idx = tid; idx < 2 * 16 * NCL * 32; idx += 512) {
+            const int e = idx & 31, blk = idx >> 5, c = blk % NCL, hq = blk / NCL;
+            sm[cfg::OFF_CL + idx] = p.cpb[(hq * NCGB + c) * 32 + e];
+        }
+    }
 #ifdef E9_ONLY_BACK
     for (int idx = tid; idx < 2 * B * GS; idx += 512) Gs[idx] = 1.0;  // (something finite for the back role to cut)
 #endif
@@ -305,11 +340,11 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 tr4(whi, &pl[4][g4], &pl[5][g4], &pl[6][g4], nullptr);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (active) {
+            if (active && (cvalid || NCP == NCOL)) {
                 unsigned char *wq = smb + dst_bytes;
 #pragma unroll
                 for (int sl = 0; sl < QW; ++sl)
-                    *reinterpret_cast<i4_t *>(wq + ((sl * 2 + chunk) * NCOL + c) * 16) =
+                    *reinterpret_cast<i4_t *>(wq + ((sl * 2 + chunk) * NCP + c) * 16) =
                         i4_t{(int)pl[sl][0], (int)pl[sl][1], (int)pl[sl][2], (int)pl[sl][3]};
             }
             const bool mine = active && cvalid && !poisoned && (bad >> 20) != 0u;
@@ -395,8 +430,8 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 af[r][2] = (int)((((g >> 16) & 0xFu) * 0x00204081u) & 0x01010101u);
                 af[r][3] = (int)((((g >> 20) & 0xFu) * 0x00204081u) & 0x01010101u);
             }
-            const unsigned char *wq = smb + (lh == 0 ? P0_BYTES : PG_BYTES) + ((l4 & 1) * NCOL + l15) * 16;
-            constexpr int PSTRIDE = 2 * NCOL * 16;  // bytes between digit planes
+            const unsigned char *wq = smb + (lh == 0 ? P0_BYTES : PG_BYTES) + ((l4 & 1) * NCP + l15) * 16;
+            constexpr int PSTRIDE = 2 * NCP * 16;  // bytes between digit planes
             // The planes go through in three batches per column tile -- {0,1,2}, {3,4,5}, {6}: 24-bit pieces of the sums,
             // each added to the int64 accumulators on its own -- one block = one (column tile, batch, row tile).  The
             // blocks are software-pipelined two deep: the MFMAs of block i+1 are issued before the sums of block i are
@@ -589,6 +624,18 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     int st_wlo = 0, st_whi = 0;
     int st_mb[4] = {0, 0, 0, 0};
     double xx_run = 0.0;  // sum_i w_i |x~_i|^2 of this wave's rows (sigma^2 and the llk are linear in it)
+    double sq_run = 0.0;  // (layout B) this lane's running share of sum_i w_i tr(C_o Sigma_i C_o^T); layout A keeps it in LDS
+    // (layout B) the lane's four means, requested from L1 / L2 with the next tile's rows (no LDS copy of the mean)
+    double muq[4] = {0.0, 0.0, 0.0, 0.0};
+    auto load_mu = [&]() {
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(mMean), 0, d * (int)sizeof(double), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+            const u2_t v2 = __builtin_amdgcn_raw_buffer_load_b64(mrs, lane_entry * 16 + 8 * (q & 1), 1024 * (q >> 1), 0);  // (past d: zeros)
+            muq[q] = __longlong_as_double(((long long)v2[1] << 32) | v2[0]);
+        }
+    };
     auto stage_row = [&](int64_t t, int lane, auto r_tag) {
         constexpr int r = decltype(r_tag)::value;
         const int ri = wave * RPW + r;
@@ -623,9 +670,13 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     auto stage_tile = [&](int64_t t, int lane) {
         {
             typedef double d2_t __attribute__((ext_vector_type(2)));
-            const d2_t m0 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 2 * lane);
-            const d2_t m1 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 + 2 * lane);
-            mu[0] = m0[0]; mu[1] = m0[1]; mu[2] = m1[0]; mu[3] = m1[1];
+            if constexpr (CLDS) {
+                mu[0] = muq[0]; mu[1] = muq[1]; mu[2] = muq[2]; mu[3] = muq[3];
+            } else {
+                const d2_t m0 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 2 * lane);
+                const d2_t m1 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 + 2 * lane);
+                mu[0] = m0[0]; mu[1] = m0[1]; mu[2] = m1[0]; mu[3] = m1[1];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) lim[q] = (128 * (q >> 1) + 2 * lane + (q & 1) < d) ? __builtin_inf() : -1.0;
         }
@@ -646,6 +697,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile_begin);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) load_row(trs, tile_begin, r);
+        if constexpr (CLDS) load_mu();
         load_pair(qbA, 6);
 #if E9_QB_EARLY
         load_pair(qbB, 4);
@@ -661,17 +713,15 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     constexpr int LROWS = LMAJ ? (KP + LPER - 1) / LPER : 0;  // buffer rows the entry-major factor takes
     // z (a, sample i): first the unused columns of the row's b partial and the pad; what does not fit goes behind K' in the row
     // (row-major factor) or entry-major behind the factor's rows (entry-major factor: the G part of every row is taken)
+    constexpr int PADC = cfg::PADC, ZIN = PADC - K - 1;  // z slots behind [w z | w] in the row's b area + pad (layout A: 17 - K)
     auto zslot = [](int a, int i) {
-        constexpr int nb = 15 - K;
-        if (a < nb) return i * GS + 16 * NTP + K + 1 + a;
-        a -= nb;
-        if (a < 2) return i * GS + 16 * NTP + 16 + a;
-        a -= 2;
+        if (a < ZIN) return i * GS + 16 * NTP + K + 1 + a;
+        a -= ZIN;
         if (LMAJ) return (LROWS + a / (LPER > 0 ? LPER : 1)) * GS + (a % (LPER > 0 ? LPER : 1)) * 32 + i;
         return i * GS + KP + a;
     };
-    static_assert(!LMAJ || LROWS + (K - (15 - K) - 2 > 0 ? (K - (15 - K) - 2 + LPER - 1) / (LPER > 0 ? LPER : 1) : 0) <= B, "entry-major z rows");
-    static_assert(16 * NTP + E9_GS_PAD >= 16 * NTP + 18 && (15 - K) + 2 + (16 * NTP - KP) >= K, "free slots of a row hold z");
+    static_assert(!LMAJ || LROWS + (K - ZIN > 0 ? (K - ZIN + LPER - 1) / (LPER > 0 ? LPER : 1) : 0) <= B, "entry-major z rows");
+    static_assert(ZIN >= 0 && (LMAJ || ZIN + (16 * NTP - KP) >= K), "free slots of a row hold z");
 
     // Where entry e of sample i's factor waits for the column waves: entry-major over the G part of the buffer when that part is
     // a whole number of 32-double blocks wide and has rows enough (k = 6, 7, 10), else in the sample's own row.
@@ -748,10 +798,17 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #pragma unroll
                 for (int c = 0; c < NCGB; ++c) accb[c][0] = accb[c][1] = 0.0;
                 double cb[LAC + 1][NCGB], xb[LAX + 1][2];
+                constexpr int NCLc = cfg::NCL;
+                const double *clp = sm + cfg::OFF_CL + kq * (NQ * NCLc * 32) + (2 * l4 + kb) * 4 + j4;
+                auto cload_lds = [&](auto q_tag) {  // (layout B) the resident column groups, requested with the x~ operands
+                    constexpr int q = decltype(q_tag)::value;
+#pragma unroll
+                    for (int c = 0; c < NCLc; ++c) cb[q % (LAC + 1)][c] = clp[(q * NCLc + c) * 32];
+                };
                 auto cload = [&](auto q_tag) {
                     constexpr int q = decltype(q_tag)::value;
 #pragma unroll
-                    for (int c = 0; c < NCGB; ++c) {
+                    for (int c = NCLc; c < NCGB; ++c) {
                         typedef unsigned u2_t __attribute__((ext_vector_type(2)));
                         const int off = (q * NCGB + c) * 256;  // (a constant once the loop is unrolled)
 #ifdef E9_EXP_CLDS  // (timing experiment, results wrong: what the loop would cost with its C operands in LDS)
@@ -817,11 +874,17 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #if !E9_B_EARLYC
                 static_for<LAC>([&](auto q_tag) { cload(q_tag); });
 #endif
-                static_for<LAX>([&](auto q_tag) { xload(q_tag); });
+                static_for<LAX>([&](auto q_tag) {
+                    xload(q_tag);
+                    cload_lds(q_tag);
+                });
                 static_for<NQ>([&](auto q_tag) {
                     constexpr int q = decltype(q_tag)::value;
                     if constexpr (q + LAC < NQ) cload(std::integral_constant<int, q + LAC>{});
-                    if constexpr (q + LAX < NQ) xload(std::integral_constant<int, q + LAX>{});
+                    if constexpr (q + LAX < NQ) {
+                        xload(std::integral_constant<int, q + LAX>{});
+                        cload_lds(std::integral_constant<int, q + LAX>{});
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < NCGB; ++c)
@@ -883,14 +946,19 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 for (int rt2 = 0; rt2 < 2; ++rt2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)  // C/D map of the 16x16 integer MFMA: row = 4 (lane >> 4) + reg
-                        Gcur[(16 * rt2 + 4 * l4 + r) * GS + 16 * wave + l15] = v[rt2][r] * qs;  // (sample-major: the solver's loads pair up into 16-byte reads; entry-major measured 2 % slower)
+                        if (!CLDS || 16 * wave + l15 < KP) Gcur[(16 * rt2 + 4 * l4 + r) * GS + 16 * wave + l15] = v[rt2][r] * qs;  // (sample-major: the solver's loads pair up into 16-byte reads; entry-major measured 2 % slower)
             }
             // the two K-split partials of b are summed by the solver in a fixed order (p0 + p1)
 #if E9_B444
 #pragma unroll
             for (int c = 0; c < NCGB; ++c) {
-                if (kq == 0) Gcur[(16 * rt + l15) * GS + 16 * NTP + 4 * c + l4] = bsum[c];
-                else if (4 * c + l4 < K + 1) B1[(16 * rt + l15) * BS + 4 * c + l4] = bsum[c];
+                if constexpr (CLDS) {
+                    const int a = 4 * c + l4;
+                    if (a < K) Gcur[(16 * rt + l15) * GS + (kq == 0 ? 16 * NTP + a : cfg::p1slot(a))] = bsum[c];
+                } else {
+                    if (kq == 0) Gcur[(16 * rt + l15) * GS + 16 * NTP + 4 * c + l4] = bsum[c];
+                    else if (4 * c + l4 < K + 1) B1[(16 * rt + l15) * BS + 4 * c + l4] = bsum[c];
+                }
             }
 #else
 #pragma unroll
@@ -937,7 +1005,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #else
                     fac.load([&](int e) { return g0[e]; }, s2);
 #pragma unroll
-                    for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a] + b1[a];
+                    for (int a = 0; a < K; ++a) z[a] = g0[16 * NTP + a] + (CLDS ? g0[cfg::p1slot(a)] : b1[a]);
 #endif
                     E9_FINE(7)   // "solve" column of the table: the solver's loads
 #ifndef E9_EXP_NOFACTOR
@@ -1040,7 +1108,8 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                     scl[L_NE + i] = run_ne + sc_ne;
                 }
             }
-            scl[wave * SQW + (PAIRS ? lane : i)] += sc_sq;
+            if constexpr (CLDS) sq_run += sc_sq;
+            else scl[wave * SQW + (PAIRS ? lane : i)] += sc_sq;
         }
         if (wave == solver) { E9_FINE(6) } else { E9_FINE(8) }  // "factor": the solver's trip; "columns": a column wave's
         // the factor, z and [wz | w] of tile rel and the W rows of tile rel - 1 are final
@@ -1054,6 +1123,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         // the only reader of the x~ tile; the next tile's rows are requested one per k-step behind the MFMAs
         {
             load_pair(qbA, 6);  // the next tile's first digit pair (the table does not depend on the tile)
+            if constexpr (CLDS) load_mu();
 #if E9_QB_EARLY
             load_pair(qbB, 4);  // ... and its second
 #endif
@@ -1116,7 +1186,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     // ---------------------------------------------------------------- epilogue (front waves)
     {
         const int lane = lane_entry, l15 = lane & 15, l4 = lane >> 4;
-        const double sq_w = wave_sum(lane < SQW ? scl[wave * SQW + lane] : 0.0);
+        const double sq_w = CLDS ? wave_sum(sq_run) : wave_sum(lane < SQW ? scl[wave * SQW + lane] : 0.0);
         const double xx_w = wave_sum(xx_run);
         if (lane == 0) {
             xxs[wave] = sq_w;
