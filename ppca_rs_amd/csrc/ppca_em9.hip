@@ -41,7 +41,7 @@ constexpr int E9_FLUSH_GROUPS = 100;
 #define E9_FRONT_PRIO 0
 #endif
 #ifndef E9_CLDS
-#define E9_CLDS 0  // 1 (round 5, "layout B"): b = X~ C on the 4 x 4 x 4 form with the first two column groups of C RESIDENT IN LDS (16 KB; the third
+#define E9_CLDS 1  // 1 (round 5, "layout B"; measured 103.7 against 100.3 EM it/s, gpurun_out/r5ab4; 0: round 4's layout): b = X~ C on the 4 x 4 x 4 form with the first two column groups of C RESIDENT IN LDS (16 KB; the third
                    // from L1 / L2), the LDS for it reclaimed at k = 10 from: digit planes packed to their real columns (6.1 KB), the second K-half
                    // partial of b in the row's free slots instead of its own array (2.8), the row stride 82 -> 78 (2), the mean re-read from L1 / L2
                    // instead of an LDS copy (2), the per-lane running sum of tr(C Sigma C^T) in a register instead of LDS (2)
@@ -59,9 +59,6 @@ constexpr int E9_FLUSH_GROUPS = 100;
                    // vmcnt), deeper look-ahead changes nothing (E9_LAC=6: 99.9).  With the C operands from LDS (timing experiment
                    // E9_EXP_CLDS, results wrong) the loop takes 2.22 k and the launch 104.8 it/s -- but LDS has 1.7 KB free where 20 KB are
                    // needed: E9_CLDS reclaims 16 for two of the three column groups.
-#if E9_B444 && !defined(PPCA_WITH_CPB)
-#error "E9_B444=1 reads PassArgs::cpb: build ppca_kernels.hip with -DPPCA_WITH_CPB as well (tools/devbuild.py passes -D flags to both)"
-#endif
 #ifndef E9_B_EARLYC
 #define E9_B_EARLYC 1  // the first steps of C operands requested before the Gram's digit pairs (their L2 latency under the integer MFMAs)
 #endif

@@ -78,7 +78,7 @@ struct GuardArgs {
     int d;
     int grid;             // workgroups of the guarded launch (= partials)
 };
-// em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (round 5 experiment, -DE9_B444=1 -DPPCA_WITH_CPB): one instruction = four blocks = (two
+// em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (round 5): one instruction = four blocks = (two
 // 4-dim groups kb) x (two 4-sample groups sb); its A operand is C^T: lane 16 k + 8 kb + 4 sb + i holds C[dim][4 c + i] with
 // dim = 128 kq + 32 (q >> 2) + 16 kb + 4 (q & 3) + k for the wave's dimension half kq, step q = 0..15 and column group c -- the same
 // value for sb = 0, 1, so a (kq, q, c) operand is 32 doubles, stored contiguously: entry (k, kb, i) at (2 k + kb) 4 + i.

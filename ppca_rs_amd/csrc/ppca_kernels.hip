@@ -155,9 +155,8 @@ __device__ __forceinline__ void qprep_body(CF C, double s2m, int d, double *qsca
             const int jj = idx / (K + 1), a2 = idx - jj * (K + 1);
             cp[idx] = (jj < d && a2 < K) ? C(jj, a2) : 0.0;
         }
-#ifdef PPCA_WITH_CPB
-        // ... and C in the operand order of em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (-DE9_B444=1 experiment; ppca_internal.hpp,
-        // CPB_DOUBLES): one contiguous 256-byte block per (dimension half, step, column group)
+        // ... and C in the operand order of em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (ppca_internal.hpp, CPB_DOUBLES): one
+        // contiguous 256-byte block per (dimension half, step, column group); the kernel copies the first two groups into LDS
         double *cb = cp + FUSED_MAX_D * (FUSED_MAX_K + 1);
         constexpr int NCGB = (K + 3) / 4;
         for (int idx = 256 * t + j; idx < 2 * 16 * NCGB * 32; idx += 256 * NB) {
@@ -167,7 +166,6 @@ __device__ __forceinline__ void qprep_body(CF C, double s2m, int d, double *qsca
             const int dim = 128 * kq + 32 * (q >> 2) + 16 * kb + 4 * (q & 3) + kk, col = 4 * c + i;
             cb[idx] = (dim < d && col < K) ? C(dim, col) : 0.0;
         }
-#endif
     }
     const int lane = j & 63, kc = j >> 6;
     const int c = 16 * t + (lane & 15);
