@@ -1,6 +1,6 @@
 """Builds libppca_hip.so (HIP kernels + C-ABI) for gfx950, in-tree.
 
-    python -m ppca_rs_amd.build [--force]
+    python -m ppca_rs_amd.build [--force]        (PPCA_FORCE_BUILD=1 in the environment: the same from any caller, e.g. __graft_entry__.build())
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels
 with the tree to the GPU box.
@@ -35,6 +35,7 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: str = LIB) -> str:
     """extra_flags / lib_path: diagnostic builds (e.g. -DPPCA_PHASE_TIMING into another .so)."""
+    force = force or os.environ.get("PPCA_FORCE_BUILD") == "1"  # (a clean-tree compile on demand: the mtime check re-uses prebuilt objects)
     if not force and not extra_flags and not needs_build():
         return LIB
     hipcc = _hipcc()

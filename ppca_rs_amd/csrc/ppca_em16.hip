@@ -29,6 +29,9 @@
 
 #include "ppca_device.hpp"
 
+#ifndef E16_X_AUX
+#define E16_X_AUX 0  // cache policy of the row loads of X (2 = nt: read once, served past the L1 that C and the digit table live in)
+#endif
 namespace ppca {
 
 constexpr int E16_QW = 7;        // signed bytes per entry
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(trs, lane_entry * 16, (wave * RPW + r) * rowbytes + 1024 * h, 0);
+            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(trs, lane_entry * 16, (wave * RPW + r) * rowbytes + 1024 * h, E16_X_AUX);
             xr[r][2 * h] = __longlong_as_double(((long long)v[1] << 32) | v[0]);
             xr[r][2 * h + 1] = __longlong_as_double(((long long)v[3] << 32) | v[2]);
         }

@@ -63,8 +63,9 @@ constexpr int E9_FLUSH_GROUPS = 100;
 #define E9_B_EARLYC 1  // the first steps of C operands requested before the Gram's digit pairs (their L2 latency under the integer MFMAs)
 #endif
 #ifndef E9_X_AUX
-#define E9_X_AUX 0  // cache policy of the row loads of X (2 = nt: L2-served, the rows are read once and would only push C out of the 32 KB
-                    // L1).  Measured: + 0.5 % (100.7-101.0 against 100.1-100.8 it/s), inside the box-to-box spread; not adopted
+#define E9_X_AUX 2  // cache policy of the row loads of X: nt (L2-served: the rows are read once and would only push the digit table and the
+                    // third column group of C out of the 32 KB L1).  Measured on layout B, two rounds interleaved: 103.9-104.1 against
+                    // 103.2-103.4 EM it/s (round 4's layout: +0.5 %, inside the spread)
 #endif
 #ifndef E9_Q_AUX
 #define E9_Q_AUX 0  // ... and of the Gram's digit table (128 KB per tile and workgroup).  Measured with 2 (nt): 90.0 against 100.7 it/s
@@ -73,8 +74,9 @@ constexpr int E9_FLUSH_GROUPS = 100;
 #define E9_LAC 4
 #endif
 #ifndef E9_QB_EARLY
-#define E9_QB_EARLY 0  // 1: the second digit pair {5,4} requested with {7,6} during the previous tile's P4a (round 5 experiment): the
-                       // first half of the Gram 2.40 -> 2.12 k cycles per tile, the b loop 2.70 -> 2.87 k, the launch 100.7 against 100.8 it/s
+#define E9_QB_EARLY 1  // the second digit pair {5,4} requested with {7,6} during the previous tile's P4a.  On round 4's layout it only moved the
+                       // wait (first half of the Gram 2.40 -> 2.12 k cycles per tile, b loop 2.70 -> 2.87 k: 100.7 against 100.8 it/s); on layout
+                       // B, whose b loop waits for 16 instead of 48 loads, + 0.3 % (with nt row loads 104.2-104.4 against 103.2-103.4)
 #endif
 #ifndef E9_PLANES_PACKED
 #define E9_PLANES_PACKED 1

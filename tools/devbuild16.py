@@ -19,6 +19,6 @@ assert all(p.wait() == 0 for p in procs)
 name = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--name=")]
 out = os.path.join(ROOT, "ppca_rs_amd", "libppca_hip_%s.so" % (name[0] if name else "dev16"))
 objs = ["/tmp/ppca_em16.dev.o", "/tmp/ppca_generic.dev.o" if timing else os.path.join(C, "ppca_generic.o")]
-objs += [os.path.join(C, f) for f in ("ppca_kernels.o", "ppca_em8.o", "ppca_llk.o", "ppca_comm.o", "ppca_capi.o")]
+objs += [os.path.join(C, f) for f in ("ppca_kernels.o", "ppca_em8.o", "ppca_em9.o", "ppca_solve4.o", "ppca_llk.o", "ppca_comm.o", "ppca_capi.o")]
 subprocess.check_call(base[:2] + ["-shared", "-fPIC", "-o", out] + objs)
 print(out)
