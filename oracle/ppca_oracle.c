@@ -827,11 +827,12 @@ void ppca_oracle_mix_llks(const double *x, int64_t n, int d, int k, int nm, cons
     double *l = (double *)malloc(sizeof(double) * ((size_t)nm * n + 1));
     for (int c = 0; c < nm; ++c)
         ppca_oracle_llks(x, n, d, k, sigmas[c], cs + (size_t)c * d * k, means + (size_t)c * d, l + (size_t)c * n);
+    double *v = (double *)malloc(sizeof(double) * ((size_t)nm + 1));
     for (int64_t i = 0; i < n; ++i) {
-        double v[64];
         for (int c = 0; c < nm; ++c) v[c] = l[(size_t)c * n + i] + log_weights[c];
         out[i] = robust_log_softnorm(v, nm);
     }
+    free(v);
     free(l);
 }
 
@@ -859,7 +860,6 @@ int ppca_oracle_mix_iterate(const double *x, const double *w, int64_t n, int d, 
                             const double *sigmas, const double *cs, const double *means,
                             const double *log_weights, const ppca_oracle_prior *prior,
                             double *sigmas_out, double *cs_out, double *means_out, double *log_weights_out) {
-    if (nm > 64) return -4;
     for (int64_t i = 0; i < n; ++i) if (w && !(w[i] > 0.0)) return -3;
     double *lp = (double *)malloc(sizeof(double) * ((size_t)n * nm + 1));
     ppca_oracle_mix_infer_cluster(x, n, d, k, nm, sigmas, cs, means, log_weights, lp); /* :283-295 */

@@ -1276,6 +1276,24 @@ static int mix_check(ppca_dataset *ds, ppca_model *const *models, int32_t nm) {
     return PPCA_OK;
 }
 
+// The mixture step's small device vectors, sized by the number of components (mix.rs:50-71 has no limit on it):
+// [0, P) maxima -> shifts | [P, 2P) new log-weights, llk | [2P, 3P) the normalised log-weights of the llk sweep |
+// [3P, ...) one int per component: rows its pass gathered;  P = nm + 1 rounded up to 8 doubles.
+struct MixAux {
+    double *shift, *out, *logw;
+    int *used;
+    size_t P;
+};
+static int mix_aux(ppca_ctx *ctx, int32_t nm, MixAux &a) {
+    a.P = ((size_t)nm + 1 + 7) & ~(size_t)7;
+    if (int rc = ensure(ctx->mixaux, ctx->mixaux_cap, sizeof(double) * 3 * a.P + sizeof(int) * (size_t)nm)) return rc;
+    a.shift = static_cast<double *>(ctx->mixaux->p);
+    a.out = a.shift + a.P;
+    a.logw = a.shift + 2 * a.P;
+    a.used = reinterpret_cast<int *>(a.shift + 3 * a.P);
+    return PPCA_OK;
+}
+
 // llks of every component -> llk[nm][n]; posteriors/lse on device.
 static int mix_posteriors(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
                           int32_t nm, BufRef &llk, BufRef &u, BufRef &lse, BufRef *logpost) {
@@ -1294,16 +1312,17 @@ static int mix_posteriors(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *mo
         if (int rc = ppca_llks_dev(ctx, ds, models[c], static_cast<double *>(llk->p) + (size_t)c * n)) return rc;
     // normalised log-weights (PPCAMix::new mix.rs:66-70), through the context's pinned staging buffer: an asynchronous
     // copy (every entry point that uses the staging ends with a synchronisation, so it is free at the next call)
-    if (int rc = ensure_hstage(ctx, sizeof(double) * 256)) return rc;
+    MixAux aux;
+    if (int rc = mix_aux(ctx, nm, aux)) return rc;
+    if (int rc = ensure_hstage(ctx, sizeof(double) * (size_t)nm)) return rc;
     double *lw = static_cast<double *>(ctx->hstage);
     double mx = log_weights[0];
     for (int c = 0; c < nm; ++c) mx = std::max(mx, log_weights[c]);
     double s = 0.0;
     for (int c = 0; c < nm; ++c) s += std::exp(log_weights[c] - mx);
     for (int c = 0; c < nm; ++c) lw[c] = log_weights[c] - mx - std::log(s);
-    double *work = static_cast<double *>(ctx->work->p);
-    HIP_TRY(hipMemcpyAsync(work + 1536, lw, sizeof(double) * nm, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(launch_mix_posteriors(static_cast<double *>(llk->p), work + 1536, ds->w, n, nm, static_cast<double *>(u->p),
+    HIP_TRY(hipMemcpyAsync(aux.logw, lw, sizeof(double) * nm, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_mix_posteriors(static_cast<double *>(llk->p), aux.logw, ds->w, n, nm, static_cast<double *>(u->p),
                                   static_cast<double *>(lse->p), logpost ? static_cast<double *>((*logpost)->p) : nullptr,
                                   ctx->stream));
     return PPCA_OK;
@@ -1312,7 +1331,6 @@ static int mix_posteriors(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *mo
 extern "C" int ppca_mix_llk(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
                             int32_t n_models, double *total_host, double *per_sample_host, double *log_posteriors_host) {
     if (!ctx || !log_weights) return fail(PPCA_ERR_INVALID, "null argument");
-    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models, n_models)) return rc;
     USE_CTX(ctx);
     const int64_t n = ds->n;
@@ -1430,7 +1448,8 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
     for (int c = 0; c < nm; ++c) off[c + 1] = off[c] + StatsLayout(models_in[c]->d, models_in[c]->k).len;
     const int64_t sums_at = off[nm], llk_at = sums_at + nm, total = llk_at + 1;
     if (int rc = ensure(ctx->mixpack, ctx->mixpack_cap, sizeof(double) * (size_t)total)) return rc;
-    if (int rc = ensure(ctx->mixaux, ctx->mixaux_cap, sizeof(double) * 1024)) return rc;
+    MixAux ax;
+    if (int rc = mix_aux(ctx, nm, ax)) return rc;
     // Every device block the step will ask for is taken HERE, before the first collective: a rank whose allocation fails
     // returns now, while no peer is inside an all-reduce it would never join (the sizes below are the largest any of the
     // K llk sweeps and component passes of this call can request).
@@ -1459,9 +1478,9 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
         if (gws_bytes)
             if (int rc = ensure(ctx->gws, ctx->gws_cap, gws_bytes)) return rc;
     }
-    if (int rc = ensure_hstage(ctx, sizeof(double) * 1024)) return rc;
+    if (int rc = ensure_hstage(ctx, sizeof(double) * ax.P + sizeof(int) * (size_t)nm)) return rc;
     double *pack = static_cast<double *>(ctx->mixpack->p);
-    double *aux = static_cast<double *>(ctx->mixaux->p);  // [0, 256): maxima -> shifts; [256, 513): new log-weights, llk
+    double *aux = ax.shift;  // maxima -> shifts
     double *work = static_cast<double *>(ctx->work->p);
     BufRef llk, u, lse;
     if (n > 0) {
@@ -1477,7 +1496,7 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
     }
     HIP_TRY(launch_mix_shift(aux, nm, ctx->stream));
     ctx->stats_llk_at = -1;
-    int *used_all = reinterpret_cast<int *>(aux + 520);  // rows each component pass gathered (diagnostic: ppca_mix_last_rows_used)
+    int *used_all = ax.used;  // rows each component pass gathered (diagnostic: ppca_mix_last_rows_used)
     for (int c = 0; c < nm; ++c) {
         const int *used_dev = nullptr;
         if (int rc = mix_component_enqueue(ctx, ds, models_in[c], ud ? ud + (size_t)c * n : nullptr, aux + c, pack + off[c],
@@ -1491,10 +1510,10 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
     }
     for (int c = 0; c < nm; ++c)  // (plain finalisation: the context has ONE slice table, the next iteration walks K models)
         if (int rc = em_finalize_impl(ctx, models_in[c], pack + off[c], prior, models_out[c], false)) return rc;
-    HIP_TRY(launch_mix_logweights(pack + sums_at, aux, pack + llk_at, nm, aux + 256, ctx->stream));
+    HIP_TRY(launch_mix_logweights(pack + sums_at, aux, pack + llk_at, nm, ax.out, ctx->stream));
     double *hs = static_cast<double *>(ctx->hstage);
-    HIP_TRY(hipMemcpyAsync(hs, aux + 256, sizeof(double) * (size_t)(nm + 1), hipMemcpyDeviceToHost, ctx->stream));
-    int *hused = reinterpret_cast<int *>(hs + 260);
+    HIP_TRY(hipMemcpyAsync(hs, ax.out, sizeof(double) * (size_t)(nm + 1), hipMemcpyDeviceToHost, ctx->stream));
+    int *hused = reinterpret_cast<int *>(hs + ax.P);
     HIP_TRY(hipMemcpyAsync(hused, used_all, sizeof(int) * (size_t)nm, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int c = 0; c < nm; ++c) log_weights_out[c] = hs[c];
@@ -1516,7 +1535,6 @@ extern "C" int ppca_mix_em_step(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *con
                                 const double *log_weights_in, int32_t n_models, const ppca_prior *prior,
                                 ppca_model *const *models_out, double *log_weights_out, double *llk_in) {
     if (!ctx || !log_weights_in || !models_out || !log_weights_out) return fail(PPCA_ERR_INVALID, "null argument");
-    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models_in, n_models)) return rc;
     if (ds->n == 0) return fail(PPCA_ERR_EMPTY, "dataset is empty");
     return mix_em_step(ctx, nullptr, ds, models_in, log_weights_in, n_models, prior, models_out, log_weights_out, llk_in);
@@ -1526,7 +1544,6 @@ extern "C" int ppca_mix_em_step_sharded(ppca_comm *comm, ppca_dataset *shard, pp
                                         const double *log_weights_in, int32_t n_models, const ppca_prior *prior,
                                         ppca_model *const *models_out, double *log_weights_out, double *llk_in) {
     if (!comm || !log_weights_in || !models_out || !log_weights_out) return fail(PPCA_ERR_INVALID, "null argument");
-    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(shard, models_in, n_models)) return rc;  // (an empty shard still takes part in the collectives)
     ppca_ctx *ctx = ppca_comm_context(comm);
     if (shard->ctx->device != ctx->device) return fail(PPCA_ERR_INVALID, "the shard does not live on the communicator's device");
@@ -1537,7 +1554,6 @@ extern "C" int ppca_mix_em_step_sharded(ppca_comm *comm, ppca_dataset *shard, pp
 extern "C" int ppca_mix_responsibilities_dev(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models,
                                              const double *log_weights, int32_t n_models, double *u_dev, double *lse_dev) {
     if (!ctx || !log_weights || !u_dev) return fail(PPCA_ERR_INVALID, "null argument");
-    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models, n_models)) return rc;
     USE_CTX(ctx);
     const int64_t n = ds->n;
@@ -1584,7 +1600,6 @@ extern "C" int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model 
                                     int32_t n_models, int32_t mode, ppca_dataset **out) {
     if (!ctx || !log_weights || !out) return fail(PPCA_ERR_INVALID, "null argument");
     if (mode < 0 || mode > 3) return fail(PPCA_ERR_INVALID, "mode must be 0..3");
-    if (n_models > 256) return fail(PPCA_ERR_UNSUPPORTED, "at most 256 mixture components");
     if (int rc = mix_check(ds, models, n_models)) return rc;
     USE_CTX(ctx);
     const int64_t n = ds->n;

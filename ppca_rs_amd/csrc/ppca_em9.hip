@@ -1,5 +1,5 @@
 // ppca_em9.hip -- the EM pass of ppca_em8.hip (eight-wave workgroup, two roles: fp64 front, int8 statistics contraction in
-// the back) with the per-sample SOLVE PIPELINED ACROSS TILES (round 4, experiment; PPCA_EM9=1 selects it):
+// the back) with the per-sample SOLVE PIPELINED ACROSS TILES (round 4; the default EM kernel, PPCA_EM9=0 selects em8_kernel):
 //
 //   em8_kernel    every front wave factors every sample of the tile and solves for z (260 + 130 vector instructions on each
 //                 of the four waves), then the waves share the columns of M^-1.  The redundancy is free in time -- the waves
@@ -18,6 +18,13 @@
 //
 // Everything else -- staging, [G | b], the fixed-point form of the back role and its guard, the cross product, the
 // epilogue -- is em8_kernel's, statement for statement; see ppca_em8.hip for the description.
+//
+// Round 5 ("layout B", E9_CLDS=1, the default): b = X~ C runs on v_mfma_f64_4x4x4 -- the instruction's four blocks are (two groups
+// of four dimensions) x (two groups of four samples), so one MFMA covers 8 samples x 4 columns x 8 dimensions and K = 10 columns
+// are three groups of four -- with the C^T operands of the first two column groups RESIDENT IN LDS in operand order; the 16 KB
+// for them come from the digit planes packed to their real columns, the second K-half's partial of b in the row's own free
+// slots, a 78-double row stride at k = 10, the mean re-read from L1 / L2 and a register running sum (Cfg9 below).  Measured
+// 103.5 against 100.3 EM it/s at N = 10 M; with nt row loads and the second digit pair requested one phase early 104.2-104.8.
 #include <atomic>
 #include <cstdlib>
 

@@ -2221,8 +2221,7 @@ hipError_t launch_reduce_sum(const double *v, const double *w, int64_t n, double
 // shifts of the mixture's component weights (mix.rs:312-323): a maximum that is not finite (no sample with a finite
 // ln w + log r: an empty shard set, or all weights zero) becomes 0 -- on the device, after the all-reduce(MAX)
 __global__ void mix_shift_kernel(double *mx, int nm) {
-    const int c = threadIdx.x;
-    if (c < nm) {
+    for (int c = threadIdx.x; c < nm; c += blockDim.x) {
         const double v = mx[c];
         mx[c] = (v - v == 0.0) ? v : 0.0;
     }
@@ -2232,18 +2231,25 @@ hipError_t launch_mix_shift(double *mx, int nm, hipStream_t s) {
     return hipGetLastError();
 }
 // new log-weights (mix.rs:324-325, :335): logsum_c = ln(sum_c) + shift_c, then robust_log_softmax (mix.rs:14-18); one
-// workgroup; out[0 .. nm) the log-weights, out[nm] = *llk (so that ONE copy brings both to the host)
+// workgroup; out[0 .. nm) the log-weights, out[nm] = *llk (so that ONE copy brings both to the host).  Any number of
+// components: out[] itself holds the logsums between the two sweeps.
 __global__ void mix_logweights_kernel(const double *sums, const double *shift, const double *llk, int nm, double *out) {
-    __shared__ double ls[256];
-    const int c = threadIdx.x;
-    ls[c] = c < nm ? log(sums[c]) + shift[c] : -INFINITY;
+    __shared__ double red[2];
+    const int t = threadIdx.x;
+    for (int c = t; c < nm; c += blockDim.x) out[c] = log(sums[c]) + shift[c];
     __syncthreads();
-    double mx = -INFINITY;
-    for (int i = 0; i < nm; ++i) mx = fmax(mx, ls[i]);  // (every thread the same order: deterministic)
-    double sm = 0.0;
-    for (int i = 0; i < nm; ++i) sm += exp(ls[i] - mx);
-    if (c < nm) out[c] = ls[c] - mx - log(sm);
-    if (c == 0) out[nm] = llk ? *llk : 0.0;
+    if (t == 0) {  // (one thread, index order: the result does not depend on the launch shape)
+        double mx = -INFINITY;
+        for (int i = 0; i < nm; ++i) mx = fmax(mx, out[i]);
+        double sm = 0.0;
+        for (int i = 0; i < nm; ++i) sm += exp(out[i] - mx);
+        red[0] = mx;
+        red[1] = log(sm);
+        out[nm] = llk ? *llk : 0.0;
+    }
+    __syncthreads();
+    const double mx = red[0], ln = red[1];
+    for (int c = t; c < nm; c += blockDim.x) out[c] = out[c] - mx - ln;
 }
 hipError_t launch_mix_logweights(const double *sums, const double *shift, const double *llk, int nm, double *out, hipStream_t s) {
     hipLaunchKernelGGL(mix_logweights_kernel, dim3(1), dim3(256), 0, s, sums, shift, llk, nm, out);

@@ -250,6 +250,33 @@ def test_mixture_against_oracle(P, oracle):
         assert _rel(mix.log_weights, lw) < RTOL
 
 
+def test_mixture_of_three_hundred_components(P, oracle):
+    """mix.rs:50-71 puts no limit on the number of components: the step's small device vectors are sized by it
+    (rounds 1-4 refused more than 256).  Broad components, so that every one keeps weight on every sample."""
+    rng = np.random.default_rng(5)
+    d, k, nm, n = 8, 2, 300, 400
+    x = rng.standard_normal((n, d))
+    x[rng.random((n, d)) < 0.1] = np.nan
+    sig = rng.uniform(0.8, 1.2, nm)
+    cs = 0.3 * rng.standard_normal((nm, d, k))
+    ms = 0.3 * rng.standard_normal((nm, d))
+    lw = np.log(rng.dirichlet(np.ones(nm) * 5))
+    ds = P.Dataset(x)
+    mix = P.PPCAMix([P.PPCAModel(sig[c_], cs[c_], ms[c_]) for c_ in range(nm)], lw)
+    assert _rel(mix.llks(ds), oracle.mix_llks(x, sig, cs, ms, lw)) < 1e-9
+    assert _rel(mix.infer_cluster(ds), oracle.mix_infer_cluster(x, sig, cs, ms, lw)) < 1e-8
+    for _ in range(2):
+        want = oracle.mix_iterate(x, sig, cs, ms, lw)
+        mix, llk = mix.iterate_with_llk(ds)
+        assert abs(llk - oracle.mix_llks(x, sig, cs, ms, lw).sum()) < 1e-8 * abs(llk)
+        sig, cs, ms, lw = want
+        for c_, mdl in enumerate(mix.models):
+            assert abs(mdl.isotropic_noise - sig[c_]) < RTOL * sig[c_]
+            assert _rel(mdl.transform, cs[c_]) < RTOL and _rel(mdl.mean, ms[c_]) < RTOL
+        assert _rel(mix.log_weights, lw) < RTOL
+    assert _rel(mix.smooth(ds).numpy(), oracle.mix_inferred(x, sig, cs, ms, lw)["smooth"]) < 1e-8
+
+
 def test_mixture_inference_outputs_against_oracle(P, oracle):
     """PPCAMix.infer / smooth / extrapolate and the InferredMaskedMix accessors (mix.rs:179-265,
     :352-515) -- GPU per-component inference + posterior-weighted combination vs the oracle's restatement."""
