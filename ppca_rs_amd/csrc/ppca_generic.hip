@@ -692,6 +692,7 @@ struct I8GemmArgs {
     // side (j fastest), then the next row block, then the next K-slice.  ncb / nrb: column / row blocks of the product.
     int xcd_map;
     int ncb, nrb;
+    int tile_rows;     // 0: the launcher's choice; 128: the 128-row tile (two workgroups per CU)
 };
 
 // KB = bytes of K per staged step (64 or 128: whole 128-byte lines per row at 128); rows padded by 16 B in LDS.
@@ -700,6 +701,29 @@ struct I8GemmArgs {
 // BUF: operands through buffer descriptors (per-thread piece offsets computed once, the K position a scalar offset:
 // no vector address arithmetic in the K loop -- the pointer form spent 2.7 vector instructions per MFMA on 64-bit
 // addresses and bounds, SQ_INSTS_VALU 338 M against SQ_INSTS_MFMA 91 M per launch); needs both operands < 2 GiB.
+// The K loop of the buffer form runs WITHOUT a workgroup barrier (round 5, late; I8_RING=0: the two-buffer loop of rounds 2-5 with its
+// barrier per step).  The LDS image is a ring of K-steps whose stages carry two monotonic LDS counters: `full` (waves that have stored
+// their pieces of the step) and `empty` (waves that have requested their fragments of it).  A wave signals a stage full at least one whole
+// step before anyone waits for it and signals it empty as soon as its fragment reads are issued (a wave's LDS operations execute in
+// order); the counters of the next step are read in the middle of a step's MFMAs, so the usual case costs no LDS round trip.
+//   256-row tile (one workgroup per CU): four stages, a step is stored into the stage freed TWO steps ago (a fast wave may run two
+//     steps ahead of the slowest), and the operands are requested as WHOLE 128-byte lines, two K-steps at a time (I8_WIDE: a K-step
+//     takes 64 bytes of each of 512 rows that lie far apart -- 64 KB of half-used lines against 32 KB of L1 -- so the second halves
+//     were fetched from L2 again; eight lanes now cover a row's 128 bytes, and the lane -> piece map alternates between a thread's row
+//     blocks so that every thread holds pieces of both steps and each step's staging is a full-width ds_write).
+//   128-row tile (two workgroups per CU): three stages, one step of slack, 64-byte requests (the wide form spills there).
+// Measured at config 4 (profiles/r05/i8gemm_ring_ab.log, i8gemm_pmc.log): 174.2 -> 168.9 ms per EM iteration; per launch the Gram
+// product 1 780 -> 1 680 us, the statistics product 1 275 -> 1 190 us.  What did NOT pay, each built and parity-green
+// (tools/experiments/i8gemm_ring_variants.patch): a three-stage ring at one step of slack (178 ms -- slower than the barrier), a
+// half-step stagger of the second wave of every SIMD (+-0), A fragments straight from global memory into the operand registers
+// (195 ms), the mask operand as packed BITS expanded by the VALU (187 ms: A costs no LDS and an eighth of the bytes, and the 48
+// VALU operations per step cost more than both).
+#ifndef I8_RING
+#define I8_RING 1
+#endif
+#ifndef I8_WIDE
+#define I8_WIDE 1
+#endif
 #ifndef I8_STAGES
 #define I8_STAGES 1  // measured at config 4 (round 2): 1 -> 254.0, 2 -> 253.4, 3 -> 253.2, 4 -> 262.4 ms (spills); the registers go to the fragments
 #endif
@@ -717,8 +741,11 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
     // 0.9-1.1e9 against SQ_ACTIVE_INST_LDS 0.4-0.6e9 per launch (round 2, gpurun_out/pmcgen).
     extern __shared__ __attribute__((aligned(16))) unsigned char i8sm[];
     constexpr int AROWS = TM, BROWS = GQS * 32;
-    unsigned char *As = i8sm;                              // [2][4][TM][16]
-    unsigned char *Bs = i8sm + 2 * 4 * AROWS * 16;         // [2][4][GQS * 32][16]
+    constexpr int NBUF = (BUF && I8_RING != 0) ? (TM == 256 ? 4 : 3) : 2;  // stages of the LDS image
+    constexpr int LAG = TM == 256 ? 2 : 1;                                  // a step is stored into the stage freed LAG steps ago
+    constexpr bool WIDE = BUF && I8_RING != 0 && I8_WIDE != 0 && TM == 256;
+    unsigned char *As = i8sm;                              // [NBUF][4][TM][16]
+    unsigned char *Bs = i8sm + NBUF * 4 * AROWS * 16;  // [NBUF][4][GQS * 32][16]
     auto slot = [](int rows, int buf, int row, int q) {    // byte offset of (row, piece q) in buffer buf
         const int g = (q & 1) * 2 + (q >> 1) * 12;         // 0, 2, 12, 14
         return ((buf * 4 + q) * rows + (row ^ g)) * 16;
@@ -839,6 +866,187 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
         // ~1 k cycles of MFMAs per SIMD) before it is staged.  (The MFMA pipe is 30 % busy in this kernel by
         // SQ_VALU_MFMA_BUSY_CYCLES; a deeper pipeline did not change that: memory latency is not what it waits for.)
         const int nsteps = (int)((kend - kbeg) / KB);
+        if constexpr (NBUF >= 3) {
+            constexpr unsigned NW = THREADS / 64;
+            unsigned *full = reinterpret_cast<unsigned *>(i8sm + NBUF * 4 * (AROWS + BROWS) * 16), *empty = full + NBUF;
+            if (tid < 2 * NBUF) full[tid] = 0u;
+            __syncthreads();
+            auto signal = [&](unsigned *ctr) {
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+            };
+            auto await = [&](const unsigned *ctr, unsigned need) {
+                for (;;) {
+                    const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if ((int)(seen - need) >= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            };
+            if constexpr (WIDE) {
+                static_assert(!WIDE || (NBUF == 4 && LAG == 2 && ST == 1), "the wide request walks pairs of steps over a four-stage ring");
+                constexpr int RPT = THREADS / 8, NA2 = TM * 8 / THREADS, NB2 = BROWS * 8 / THREADS;
+                static_assert(NA2 % 2 == 0 && NB2 % 2 == 0 && RPT % 16 == 0, "row blocks come in pairs");
+                typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+                const int tr = tid >> 3, t8 = tid & 7;
+                const bool selhi = (t8 & 4) != 0;  // this thread's even row blocks hold the second step of a pair
+                gi4_t wa[NA2], wb[NB2];
+                unsigned woa[NA2], wob[NB2];
+#pragma unroll
+                for (int u = 0; u < NA2; ++u) {
+                    const int r = RPT * u + ((u & 1) ? ((tr + 1) & (RPT - 1)) : tr), q8 = t8 ^ ((u & 1) << 2);
+                    const int64_t row = m0 + r;
+                    woa[u] = row < g.M ? (unsigned)(row * g.lda + 16 * q8) : 0x80000000u;
+                }
+#pragma unroll
+                for (int u = 0; u < NB2; ++u) {
+                    const int r = RPT * u + ((u & 1) ? ((tr + 1) & (RPT - 1)) : tr), q8 = t8 ^ ((u & 1) << 2);
+                    const int64_t col = n0 + (r & 31);
+                    wob[u] = col < g.N ? (unsigned)((r >> 5) * g.plane + col * g.ldb + 16 * q8) : 0x80000000u;
+                }
+                // where this lane's piece of half h goes inside a stage: row block 2 j + (selhi ^ h), piece t8 & 3
+                const int qq = t8 & 3, gq = (qq & 1) * 2 + (qq >> 1) * 12;
+                int la[2], lb[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool odd = selhi != (h != 0);
+                    const int rb = odd ? RPT + ((tr + 1) & (RPT - 1)) : tr;
+                    la[h] = (qq * AROWS + (rb ^ gq)) * 16;
+                    lb[h] = (qq * BROWS + (rb ^ gq)) * 16;
+                }
+                auto fetchw = [&](int64_t k0) {
+#pragma unroll
+                    for (int u = 0; u < NA2; ++u) {
+                        const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)woa[u], (int)k0, 0);
+                        wa[u] = gi4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB2; ++u) {
+                        const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)wob[u], (int)k0, 0);
+                        wb[u] = gi4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+                    }
+                };
+                auto stashw = [&](int h, int stage) {
+                    const bool odd = selhi != (h != 0);
+                    unsigned char *ad = As + stage * (4 * AROWS * 16) + la[h], *bd = Bs + stage * (4 * BROWS * 16) + lb[h];
+#pragma unroll
+                    for (int j = 0; j < NA2 / 2; ++j) {
+                        gi4_t v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = odd ? wa[2 * j + 1][e] : wa[2 * j][e];
+                        *reinterpret_cast<gi4_t *>(ad + 2 * RPT * j * 16) = v;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB2 / 2; ++j) {
+                        gi4_t v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = odd ? wb[2 * j + 1][e] : wb[2 * j][e];
+                        *reinterpret_cast<gi4_t *>(bd + 2 * RPT * j * 16) = v;
+                    }
+                };
+                fetchw(kbeg);
+                stashw(0, 0);
+                signal(full + 0);
+                stashw(1, 1);
+                signal(full + 1);
+                fetchw(kbeg + 2 * KB);
+                unsigned pf = 0u, pe = 0u;
+                auto step = [&](int i, int h) {  // h = i & 1: step q = i + 2 is half h of its pair
+                    const int st = i & 3;
+                    const unsigned nf = NW * (unsigned)((i >> 2) + 1);
+                    if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)pf) - nf) < 0) await(full + st, nf);
+                    gi4_t fa[4], fb[GQS];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const gi4_t *>(As + slot(AROWS, st, 64 * wm + 16 * a + l15, l4));
+#pragma unroll
+                    for (int s = 0; s < GQS; ++s) fb[s] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, st, s * 32 + 16 * wn + l15, l4));
+                    signal(empty + st);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int q = i + 2, sq = q & 3;
+                    if (q < nsteps) {  // (uniform)
+                        const unsigned ne = NW * (unsigned)(q >> 2);
+                        if (i >= 2 && (int)((unsigned)__builtin_amdgcn_readfirstlane((int)pe) - ne) < 0) await(empty + sq, ne);
+                        stashw(h, sq);
+                        signal(full + sq);
+                        if (h == 1) fetchw(kbeg + (int64_t)(q + 1) * KB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < GQS / 2; ++s)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pf = __hip_atomic_load(full + ((st + 1) & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pe = __hip_atomic_load(empty + ((sq + 1) & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = GQS / 2; s < GQS; ++s)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                for (int i = 0; i < nsteps; i += 2) {
+                    step(i, 0);
+                    if (i + 1 < nsteps) step(i + 1, 1);  // (uniform)
+                }
+            } else {
+            // LAG: the stage a step is stored into was freed LAG steps ago (a fast wave may run LAG steps ahead of the slowest one);
+            // steps 0 .. NBUF - LAG - 1 staged up front, steps NBUF - LAG .. NBUF - LAG - 1 + ST in registers.
+            static_assert(LAG >= 1 && LAG < NBUF, "ring lag");
+#pragma unroll
+            for (int j = 0; j < NBUF - LAG; ++j) {
+                fetch(kbeg + (int64_t)j * KB, 0);
+                stash(j, 0);
+                signal(full + j);
+            }
+#pragma unroll
+            for (int j = 0; j < ST; ++j) fetch(kbeg + (int64_t)(NBUF - LAG + j) * KB, j);
+            // the counters of the NEXT step are read in the middle of a step's MFMAs and looked at when that step begins: the usual case
+            // (everyone has arrived) costs no LDS round trip at the head of the step
+            unsigned pf = 0u, pe = 0u;
+            auto step = [&](int i, int rs) {
+                const int st = i % NBUF;
+                const unsigned nf = NW * (unsigned)(i / NBUF + 1);
+                if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)pf) - nf) < 0) await(full + st, nf);
+                gi4_t fa[4], fb[GQS];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const gi4_t *>(As + slot(AROWS, st, 64 * wm + 16 * a + l15, l4));
+#pragma unroll
+                for (int s = 0; s < GQS; ++s) fb[s] = *reinterpret_cast<const gi4_t *>(Bs + slot(BROWS, st, s * 32 + 16 * wn + l15, l4));
+                signal(empty + st);        // (the reads above are ahead of this add in the wave's LDS queue)
+                __builtin_amdgcn_sched_barrier(0);
+                // step q (register set rs) goes to the stage step i - LAG was read from, behind the fragment requests
+                const int q = i + NBUF - LAG, sq = q % NBUF;
+                if (q < nsteps) {  // (uniform)
+                    const unsigned ne = NW * (unsigned)(q / NBUF);
+                    if (i >= LAG && (int)((unsigned)__builtin_amdgcn_readfirstlane((int)pe) - ne) < 0) await(empty + sq, ne);
+                    stash(sq, rs);
+                    signal(full + sq);
+                    fetch(kbeg + (int64_t)(q + ST) * KB, rs);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < GQS / 2; ++s)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                pf = __hip_atomic_load(full + (st + 1 == NBUF ? 0 : st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pe = __hip_atomic_load(empty + (sq + 1 == NBUF ? 0 : sq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = GQS / 2; s < GQS; ++s)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[s], acc[a][s], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (int i = 0; i < nsteps; i += ST) {
+#pragma unroll
+                for (int j = 0; j < ST; ++j)
+                    if (i + j < nsteps) step(i + j, j);  // (uniform)
+            }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < ST; ++j) fetch(kbeg + (int64_t)j * KB, j);
         stash(0, 0);
@@ -855,6 +1063,7 @@ __global__ __launch_bounds__(2 * TM, 2) void i8gemm_kernel(I8GemmArgs g) {  // t
                     __syncthreads();
                 }
             }
+        }
         }
     } else {
         fetch(kbeg, 0);
@@ -2317,7 +2526,8 @@ __global__ void add_partial_kernel(double *out, int64_t ldo, const double *part,
 
 template <int TM, bool BUF>
 static hipError_t launch_i8gemm_t(const I8GemmArgs &g, dim3 grid, hipStream_t s) {
-    const size_t lds = 2 * (TM + GQS * 32) * 64;
+    constexpr int nbuf = (BUF && I8_RING != 0) ? (TM == 256 ? 4 : 3) : 2;
+    const size_t lds = (size_t)nbuf * (TM + GQS * 32) * 64 + (nbuf >= 3 ? 64 : 0);  // (+ the ring's counters)
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
@@ -2369,7 +2579,7 @@ static hipError_t launch_i8gemm(const I8GemmArgs &g, hipStream_t s) {
         return !(e && atoi(e) == 0);
     }();
     I8GemmArgs h = g;
-    const bool tall = tm == 256 && ((g.ksplit == 0 && g.M >= 4096) || (s256 && g.M >= 1024));  // (the Gram: one row per sample; S at d >= 1024)
+    const bool tall = tm == 256 && g.tile_rows != 128 && ((g.ksplit == 0 && g.M >= 4096) || (s256 && g.M >= 1024));  // (the Gram: one row per sample; S at d >= 1024)
     const int tmr = tall ? 256 : 128;
     h.ncb = (int)((g.N + 31) / 32);
     h.nrb = (int)((g.M + tmr - 1) / tmr);
@@ -2594,6 +2804,11 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
             // G = Mask . Q on the int8 MFMA (exact integer accumulation) unless the guard raised flags[0]
             I8GemmArgs q{};
             q.A = W.A; q.lda = W.dpad; q.Bt = W.BtQ; q.ldb = W.dpad; q.plane = kp * (int64_t)W.dpad;
+            static const int gram_tile = [] {  // PPCA_I8GEMM_GRAM_TM=128: the Gram product on 128-row tiles (A/B runs)
+                const char *e = getenv("PPCA_I8GEMM_GRAM_TM");
+                return (e && atoi(e) == 128) ? 128 : 0;
+            }();
+            q.tile_rows = gram_tile;
             q.M = nc; q.N = kp; q.K = W.dpad; q.scale = W.scaleQ; q.out = W.G; q.ldo = kp; q.accumulate = 0;
             q.guard = W.flags;
             GTRY(launch_i8gemm(q, s));
