@@ -666,6 +666,10 @@ def test_full_size_properties(P):
                                             (300, 70, 20, 0.3, False), (200, 513, 10, 0.3, False),
                                             (301, 80, 40, 0.3, False), (203, 64, 32, 0.3, False), (7, 40, 17, 0.2, False),
                                             (130, 70, 48, 0.2, False), (66, 90, 49, 0.1, False),
+                                            # both int8 products on the 256-row tile (>= 4096 samples, d >= 1024) with ODD numbers of
+                                            # K-steps (17 over the dimensions, 67 over the samples): the wide request of the ring loop
+                                            # walks K-steps in pairs
+                                            (4230, 1080, 18, 0.3, False),
                                             # state sizes beyond 64 (round 5; the reference bounds k nowhere, ppca_model.rs:51-70): fp64
                                             # contractions + the workgroup-per-matrix solver of ppca_generic.hip, up to the 128 x 128
                                             # matrix that 160 KB of LDS hold
