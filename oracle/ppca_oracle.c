@@ -44,6 +44,20 @@
 
 static int is_finite(double v) { return isfinite(v); }
 
+/* test infrastructure: the number of OpenMP threads the loops below use (many tiny calls on a many-core host --
+ * a mixture of hundreds of components over a few hundred samples -- spend their time starting teams); returns the
+ * previous value */
+int ppca_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    const int old = omp_get_max_threads();
+    if (n >= 1) omp_set_num_threads(n);
+    return old;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 int ppca_oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -98,6 +98,11 @@ def num_threads() -> int:
     return int(lib().ppca_oracle_num_threads())
 
 
+def set_threads(n: int) -> int:
+    """OpenMP threads of the oracle's loops; returns the previous value (tests with very many tiny calls on a many-core host)."""
+    return int(lib().ppca_oracle_set_threads(int(n)))
+
+
 def quadratic_form(sigma, c, x) -> float:
     c = _a(c); x = _a(x).ravel()
     return float(lib().ppca_oracle_quadratic_form(_p(c), c.shape[0], c.shape[1], C.c_double(sigma), _p(x)))

@@ -17,6 +17,10 @@ def oracle():
     from oracle import ppca_oracle
 
     ppca_oracle.build()
+    # The tests call the oracle thousands of times on a few hundred samples: on a 128-core host the OpenMP teams of such calls cost
+    # more than the loops (a 300-component mixture over 400 samples: 20 minutes on all cores, half a second on two).
+    if ppca_oracle.num_threads() > 16:
+        ppca_oracle.set_threads(16)
     return ppca_oracle
 
 
