@@ -1404,6 +1404,20 @@ __global__ __launch_bounds__(256) void reduce_wguard_kernel(const double *part, 
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         if (e < elen && src) {
             int q = p0;
+            // sixteen partials requested before the first is added (a thread's four running sums take them in the order of the
+            // four-at-a-time loop below: the result does not change): the launch is bound by the bytes it keeps in flight
+            for (; q + 16 <= p1; q += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = src[(int64_t)(q + u) * elen + e];
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    s0 += v[u];
+                    s1 += v[u + 1];
+                    s2 += v[u + 2];
+                    s3 += v[u + 3];
+                }
+            }
             for (; q + 4 <= p1; q += 4) {
                 s0 += src[(int64_t)q * elen + e];
                 s1 += src[(int64_t)(q + 1) * elen + e];

@@ -10,7 +10,7 @@ for f in mfma_peak.txt mfma_peak.json traffic.json traffic_cfg4.json traffic_cfg
   [ -f $S/$f ] && cp $S/$f $D/$f
 done
 cp $S/cliff_d*_k*.json $D/cliff/ 2>/dev/null || true
-pick() { ls $S/$1/*/*$2 2>/dev/null | head -1; }
+pick() { ls -t $S/$1/*/*$2 2>/dev/null | head -1; }  # (the newest: gpurun_out/ keeps the files of earlier leases)
 for p in "kt bench_n10m" "kt_n1250k n1250k" "kt_out1 bench_n10m_outliers1" "kt_cfg5 bench_cfg5" "kt_cfg4 bench_cfg4"; do set -- $p; f=$(pick $1 kernel_stats.csv); [ -n "$f" ] && cp $f $D/$2_kernel_stats.csv; done
 for p in "pmc_fetch pmc_n10m_FETCH_SIZE" "pmc_write pmc_n10m_WRITE_SIZE" "pmc_mfma pmc_n1m_mfma" "pmc_inst pmc_n1m_inst"; do set -- $p; f=$(pick $1 counter_collection.csv); [ -n "$f" ] && cp $f $D/$2_counter_collection.csv; done
 python3 tools/make_profiles_r05.py
