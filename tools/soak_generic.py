@@ -1,7 +1,7 @@
 """Soak of the split pipeline at config 4's shape (N = 400 k): forty statistics passes must be bit-identical (a race in the int8 GEMM's ring would show),
 then ten EM iterations.  Diagnostic; run on the GPU box:  python tools/soak_generic.py"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ppca_rs_amd as P
 from ppca_rs_amd import _lib
