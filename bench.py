@@ -245,6 +245,107 @@ def sustained_mfma_from_profiles():
     return None
 
 
+SECONDARY = {
+    # BASELINE.json configurations 2, 4 and 5 as SHORT legs of the default run, so that the driver's clock sees them too (round 5's
+    # review: five rounds of config-4 / config-5 numbers were only ever on the builder's clock).  No CPU leg for them.
+    "cfg2": dict(n=1_000_000, d=256, k=10, mask=0.3, mask_kind=0, mask_run=0, warmup=3, steps=20, mixture=0),
+    "cfg4": dict(n=2_000_000, d=1024, k=64, mask=0.5, mask_kind=1, mask_run=512, warmup=1, steps=3, mixture=0),
+    "cfg5": dict(n=5_000_000, d=256, k=10, mask=0.3, mask_kind=0, mask_run=0, warmup=9, steps=11, mixture=8),
+}
+
+
+def secondary_leg(name: str, ctx, sync) -> dict:
+    """One BASELINE configuration other than the headline, on one GPU, in this process: value, ms per step and the roofline fraction
+    bench.py --config N reports for it (same data seeds, same start models, same timed regions: EM configurations = kernel time by
+    HIP events over the timed steps against the algorithmic fp64 flops; the mixture = the one-pass bytes over the step time)."""
+    import ctypes as C
+
+    import ppca_rs_amd as P
+    from ppca_rs_amd import _lib
+    from ppca_rs_amd.distributed import ShardedEM, ShardedMixEM
+
+    sp = SECONDARY[name]
+    n, d, k = sp["n"], sp["d"], sp["k"]
+
+    def generate(c_true, mean_true, row_offset, n_rows, seed):
+        truth = P.PPCAModel(0.1, c_true, mean_true)
+        spec = _lib.SynthSpec(row_offset, n_rows, d, k, 0.1, sp["mask"], sp["mask_kind"], sp["mask_run"], seed,
+                              truth._c.ctypes.data_as(_lib.c_double_p), truth._mean.ctypes.data_as(_lib.c_double_p))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ppca_dataset_generate(ctx.handle, C.byref(spec), C.byref(h)))
+        return P.Dataset._wrap(h, ctx)
+
+    nm = sp["mixture"]
+    if nm:
+        blk = 65536
+        comps = [(np.random.default_rng(1051 + 10 * c).standard_normal((d, k)), 3.0 * np.random.default_rng(1052 + 10 * c).standard_normal(d))
+                 for c in range(nm)]
+        parts = [generate(comps[(b0 // blk) % nm][0], comps[(b0 // blk) % nm][1], b0, min(n, b0 + blk) - b0, 1053) for b0 in range(0, n, blk)]
+        data = P.Dataset.concat(parts)
+        del parts
+        ctx.trim()
+        start = P.PPCAMix([P.PPCAModel(1.0, np.random.default_rng(2051 + c).standard_normal(d * k).reshape((k, d)).T.copy(), np.zeros(d))
+                           for c in range(nm)], np.zeros(nm))
+        em = ShardedMixEM(data, start)
+    else:
+        data = generate(np.random.default_rng(1011).standard_normal((d, k)), np.random.default_rng(1012).standard_normal(d), 0, n, 1013)
+        start = P.PPCAModel(1.0, np.random.default_rng(2011).standard_normal(d * k).reshape((k, d)).T.copy(), np.zeros(d))
+        em = ShardedEM(data, start)
+    for _ in range(sp["warmup"]):
+        em.step()
+    sync()
+    ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(sp["steps"]):
+        em.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = ctx.kernel_time(reset=True)
+    ctx.last_fallback()  # (drops the second stages' events)
+    ctx.enable_timing(False)
+    t_step = elapsed / sp["steps"]
+    m_obs = d * (1.0 - sp["mask"])
+    leg = {"workload": f"N={n} x d={d}, state_size={k}, {int(100 * sp['mask'])}% {'block' if sp['mask_kind'] else 'iid'} masked"
+                       + (f", mixture of {nm} components" if nm else ""),
+           "value": 1.0 / t_step, "unit": "mixture EM iters/sec" if nm else "EM iters/sec", "ms_per_step": 1e3 * t_step,
+           "steps": sp["steps"], "warmup": sp["warmup"]}
+    if nm:
+        used = (C.c_int64 * nm)()
+        _lib.check(_lib.lib().ppca_mix_last_rows_used(ctx.handle, used, nm))
+        rows_gathered = [int(v) for v in used]
+        bytes_step = n * algorithmic_bytes_per_sample(d)
+        flops_step = nm * n * algorithmic_flops_llk_per_sample(k, m_obs) + sum(rows_gathered) * algorithmic_flops_per_sample(d, k, m_obs)
+        leg["roofline"] = {"bound": "hbm", "achieved": bytes_step / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": bytes_step / t_step / 1e9 / HBM_PEAK_GBS,
+                           "fp64_frac_executed": flops_step / t_step / 1e12 / FP64_PEAK_TFLOPS,
+                           "rows_gathered_fraction_of_K_x_N": sum(rows_gathered) / float(nm * n),
+                           "note": "frac = ONE-pass bytes (N x 2088 B) / step time / HBM peak, as bench.py --config 5"}
+        traffic_file = "profiles/r06/traffic_cfg5.json"
+    else:
+        kern_avg = kern_ms / max(launches, 1) * 1e-3
+        flops_step = n * algorithmic_flops_per_sample(d, k, m_obs)
+        leg["roofline"] = {"bound": "mfma", "achieved": flops_step / kern_avg / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flops_step / kern_avg / 1e12 / FP64_PEAK_TFLOPS, "kernel_avg_ms": 1e3 * kern_avg, "kernel_launches": launches,
+                           "note": "algorithmic fp64 flops / the pass's HIP-event time (the EM kernel; config 4: every kernel of the split "
+                                   "pipeline as one region), as bench.py --config N"}
+        traffic_file = {"cfg2": "profiles/r06/traffic.json", "cfg4": "profiles/r06/traffic_cfg4.json"}[name]
+    leg["traffic_source"] = None
+    for rel in (traffic_file, traffic_file.replace("r06", "r05")):
+        try:
+            with open(os.path.join(ROOT, rel)) as fh:
+                tj = json.load(fh)
+            leg["traffic_bytes_per_sample"] = tj["hbm_bytes_per_sample"]
+            leg["traffic_source"] = f"{rel} (commit {tj.get('commit')}; PMC FETCH_SIZE / WRITE_SIZE passes, not measured in this run)"
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    if not nm:
+        em.close()
+    del em, data
+    ctx.trim()
+    return leg
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,7 +374,11 @@ def main() -> None:
                          "headline 10M x 256 x 10 = the default; 4: 2M x 1024 x 64, 50%% block-masked, generic pipeline; "
                          "5: mixture of 8 components, 5M x 256 x 10); 0 = take --n/--d/--k/--mask as given")
     ap.add_argument("--components", type=int, default=8, help="config 5: number of mixture components")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="the default run (one GPU, the headline configuration) also times short legs of BASELINE configurations 2, 4 and "
+                         "5 after the headline region and reports them under \"secondary\"; this switch leaves them out")
     args = ap.parse_args()
+    default_run = args.config in (0, 3) and (args.n, args.d, args.k, args.mask) == (10_000_000, 256, 10, 0.3) and args.outliers == 0 and args.gram == "auto"
     mask_kind, mask_run = 0, 0
     if args.config == 1:
         args.n, args.d, args.k, args.mask = 10_000, 32, 4, 0.0
@@ -625,9 +730,23 @@ def main() -> None:
                 out["cpu_baseline"] = cpu_baseline(shard, start, n, d, k, min(args.cpu_rows, rows_local))
         else:
             out["cpu_baseline"] = None
+        if world == 1 and default_run and not args.no_secondary:
+            # BASELINE configurations 2, 4, 5 on the same clock as the headline: short legs, after the headline's dataset is released
+            em.close()
+            del em, shard
+            em = None
+            ctx.trim()
+            out["secondary"] = {}
+            for name in ("cfg2", "cfg4", "cfg5"):
+                t_leg = time.perf_counter()
+                try:
+                    out["secondary"][name] = secondary_leg(name, ctx, sync)
+                except Exception as e:  # noqa: BLE001  (a failed leg must not cost the headline line)
+                    out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"}
+                out["secondary"][name]["leg_wall_s"] = time.perf_counter() - t_leg
         print(json.dumps(out), flush=True)
 
-    if not mixture:
+    if not mixture and em is not None:
         em.close()
     if comm is not None:
         comm.close()

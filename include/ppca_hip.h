@@ -314,7 +314,7 @@ int ppca_ctx_set_grid_limit(ppca_ctx *ctx, int32_t n_workgroups);
 int ppca_debug_counters(ppca_ctx *ctx, int64_t *out8, int32_t reset);
 
 /* Which Gram engine the fused passes use for this model: 0 = int8-sliced MFMA with exact integer accumulation,
- * 1 = fp64 MFMA.  Decided on the device per model by a dynamic-range guard (the int8 form keeps 54 bits below each
+ * 1 = fp64 MFMA.  Decided on the device per model by a dynamic-range guard (the int8 form keeps 62 bits below each
  * column maximum of vech(c c^T); a model whose rows of C span many orders of magnitude, or whose sigma^2 lies
  * below that resolution, takes the fp64 form; see ppca_kernels.hip, qprep_kernel).  Stands where the reference
  * computes C_o^T C_o in f64 (output_covariance.rs:57-70).  Synchronises. */

@@ -1294,6 +1294,98 @@ static int mix_aux(ppca_ctx *ctx, int32_t nm, MixAux &a) {
     return PPCA_OK;
 }
 
+// ---- the multi-component form (round 6): components of ONE state size on the fused path, at most MIX_MAX of them, the int8 engine
+// behind its guard (PPCA_MIX_MULTI=0: component by component, as rounds 2-5)
+static bool mix_multi_ok(const ppca_dataset *ds, ppca_model *const *models, int nm) {
+    static const bool on = [] {
+        const char *e = getenv("PPCA_MIX_MULTI");
+        return !(e && atoi(e) == 0);
+    }();
+    if (!on || nm < 1 || nm > MIX_MAX || ds->n <= 0 || ds->n >= ((int64_t)1 << 31)) return false;
+    if (fused_gram_mode() != 0 || !mix_llk8_available()) return false;
+    for (int c = 0; c < nm; ++c)
+        if (ppca_path_kind(models[c]->d, models[c]->k) != 1 || models[c]->k != models[0]->k) return false;
+    return true;
+}
+// One slice-table block per component in ctx->mixq; a slot whose (device buffer, write stamp) is not its model's is rebuilt -- all
+// stale slots in ONE qprep launch.  tab[c] = the component's block.
+static int mix_tables(ppca_ctx *ctx, ppca_model *const *models, int nm, void **tab) {
+    const size_t stride = (fused_qtab_bytes() + 255) & ~(size_t)255;
+    if (int rc = ensure(ctx->mixq, ctx->mixq_cap, stride * MIX_MAX)) return rc;
+    ctx->mixq_stride = stride;
+    if (ctx->mixq->p != ctx->mixq_base) {  // a new block: the guard words start at zero (the ticket counters of the reductions)
+        HIP_TRY(hipMemsetAsync(ctx->mixq->p, 0, stride * MIX_MAX, ctx->stream));
+        ctx->mixq_base = ctx->mixq->p;
+        ctx->mixq_slots.assign(MIX_MAX, std::make_pair((const void *)nullptr, (uint64_t)0));
+    }
+    bool stale = false;
+    MixTabArgs a{};
+    a.d = models[0]->d;
+    a.nm = nm;
+    for (int c = 0; c < nm; ++c) {
+        tab[c] = static_cast<char *>(ctx->mixq->p) + stride * c;
+        a.model[c] = models[c]->p();
+        a.tab[c] = tab[c];
+        if (ctx->mixq_slots[c] != std::make_pair((const void *)models[c]->buf->p, models[c]->stamp)) stale = true;
+    }
+    if (stale) {
+        HIP_TRY(launch_qprep_multi(models[0]->k, a, ctx->stream));
+        for (int c = 0; c < nm; ++c) ctx->mixq_slots[c] = std::make_pair((const void *)models[c]->buf->p, models[c]->stamp);
+    }
+    return PPCA_OK;
+}
+// The llk sweeps of all components in one launch (X from HBM once: the workgroups of an XCD walk the same rows for the different
+// components, ppca_llk.hip), then per component the fp64 instantiation behind its table's guard flags (returns at once unless the
+// component's model tripped the dynamic-range guard).
+static int mix_llk_sweeps_multi(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, int nm, double *llk, void **tab) {
+    const int64_t n = ds->n;
+    const int k = models[0]->k;
+    const int grid1 = fused_grid(n, ctx->n_cu);
+    if (int rc = ensure(ctx->scal, ctx->scal_cap, sizeof(double) * ((size_t)grid1 * 8 + 16))) return rc;
+    MixLlkArgs m{};
+    m.X = ds->X;
+    m.ldx = ds->d;
+    m.n = n;
+    m.d = ds->d;
+    m.nm = nm;
+    const int grid = ctx->n_cu;
+    m.runs_per_xcd = mix_llk_runs_per_xcd(grid, nm);
+    for (int c = 0; c < nm; ++c) {
+        m.model[c] = models[c]->p();
+        m.tab[c] = tab[c];
+        m.llks[c] = llk + (size_t)c * n;
+    }
+    HIP_TRY(launch_mix_llk8(k, grid, m, ctx->stream));
+    for (int c = 0; c < nm; ++c) {
+        PassArgs a{};
+        a.X = ds->X;
+        a.ldx = ds->d;
+        a.w = ds->w;
+        a.n = n;
+        a.d = ds->d;
+        a.model = models[c]->p();
+        a.scal_part = static_cast<double *>(ctx->scal->p);
+        a.llks = llk + (size_t)c * n;
+        fused_qtab_layout(tab[c], a);
+        a.skip_qprep = 1;
+        HIP_TRY(launch_pass_post_fp64(k, grid1, a, ctx->stream));
+    }
+    return PPCA_OK;
+}
+// normalised log-weights (PPCAMix::new mix.rs:66-70) into aux.logw, through the context's pinned staging buffer: an asynchronous
+// copy (every entry point that uses the staging ends with a synchronisation, so it is free at the next call)
+static int mix_upload_logw(ppca_ctx *ctx, const double *log_weights, int nm, const MixAux &aux) {
+    if (int rc = ensure_hstage(ctx, sizeof(double) * (size_t)nm)) return rc;
+    double *lw = static_cast<double *>(ctx->hstage);
+    double mx = log_weights[0];
+    for (int c = 0; c < nm; ++c) mx = std::max(mx, log_weights[c]);
+    double s = 0.0;
+    for (int c = 0; c < nm; ++c) s += std::exp(log_weights[c] - mx);
+    for (int c = 0; c < nm; ++c) lw[c] = log_weights[c] - mx - std::log(s);
+    HIP_TRY(hipMemcpyAsync(aux.logw, lw, sizeof(double) * nm, hipMemcpyHostToDevice, ctx->stream));
+    return PPCA_OK;
+}
+
 // llks of every component -> llk[nm][n]; posteriors/lse on device.
 static int mix_posteriors(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *models, const double *log_weights,
                           int32_t nm, BufRef &llk, BufRef &u, BufRef &lse, BufRef *logpost) {
@@ -1308,20 +1400,17 @@ static int mix_posteriors(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *mo
         if (int rc = ensure(ctx->mix[3], ctx->mix_cap[3], sizeof(double) * (size_t)nm * n)) return rc;
         *logpost = ctx->mix[3];
     }
-    for (int c = 0; c < nm; ++c)
-        if (int rc = ppca_llks_dev(ctx, ds, models[c], static_cast<double *>(llk->p) + (size_t)c * n)) return rc;
-    // normalised log-weights (PPCAMix::new mix.rs:66-70), through the context's pinned staging buffer: an asynchronous
-    // copy (every entry point that uses the staging ends with a synchronisation, so it is free at the next call)
+    if (mix_multi_ok(ds, models, nm)) {
+        void *tab[MIX_MAX];
+        if (int rc = mix_tables(ctx, models, nm, tab)) return rc;
+        if (int rc = mix_llk_sweeps_multi(ctx, ds, models, nm, static_cast<double *>(llk->p), tab)) return rc;
+    } else {
+        for (int c = 0; c < nm; ++c)
+            if (int rc = ppca_llks_dev(ctx, ds, models[c], static_cast<double *>(llk->p) + (size_t)c * n)) return rc;
+    }
     MixAux aux;
     if (int rc = mix_aux(ctx, nm, aux)) return rc;
-    if (int rc = ensure_hstage(ctx, sizeof(double) * (size_t)nm)) return rc;
-    double *lw = static_cast<double *>(ctx->hstage);
-    double mx = log_weights[0];
-    for (int c = 0; c < nm; ++c) mx = std::max(mx, log_weights[c]);
-    double s = 0.0;
-    for (int c = 0; c < nm; ++c) s += std::exp(log_weights[c] - mx);
-    for (int c = 0; c < nm; ++c) lw[c] = log_weights[c] - mx - std::log(s);
-    HIP_TRY(hipMemcpyAsync(aux.logw, lw, sizeof(double) * nm, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = mix_upload_logw(ctx, log_weights, nm, aux)) return rc;
     HIP_TRY(launch_mix_posteriors(static_cast<double *>(llk->p), aux.logw, ds->w, n, nm, static_cast<double *>(u->p),
                                   static_cast<double *>(lse->p), logpost ? static_cast<double *>((*logpost)->p) : nullptr,
                                   ctx->stream));
@@ -1430,6 +1519,134 @@ extern "C" int ppca_mix_component_stats(ppca_ctx *ctx, ppca_dataset *ds, const p
 //   shifts on the device (non-finite -> 0); per component: weights exp(u - shift), their sum, row selection, the
 //   gathered weighted EM pass (:320-328)            [ONE all-reduce(SUM) of [K statistics | K sums | llk]]
 //   K finalisations (identical on every rank); new log-weights log_softmax(ln sum_c + shift_c) (:324-325, :335)
+// The step in its multi-component form (mix_multi_ok; no mean prior): every stage that rounds 2-5 launched once per component is ONE
+// launch over all of them, except the gathered EM passes themselves and their (idle) fp64 second stages:
+//   slice tables of the K models (cached per model content; built by the previous step's finalisation)        [0-1 launch]
+//   mix_llk8_kernel: K llk sweeps, X from HBM once; K fp64 instantiations behind the guard flags (idle)      [1 + K]
+//   responsibilities + per-block maxima / llk partials; second stage -> K maxima, llk                        [2]
+//                                                       [all-reduce(MAX) of K doubles when sharded]; shifts  [1]
+//   row selection of the K components: counts, scan, scatter (+ weight partials), weight sums + row counts   [4]
+//   K gathered weighted EM passes (each on its own partials, bounds and guard words)                         [K]
+//   reduction + verdict of the K passes; K x (fp64 pass + second reduction) behind the verdicts (idle)       [1 + 2 K]
+//                                      [ONE all-reduce(SUM) of [K statistics | K sums | llk] when sharded]
+//   K finalisations + the K NEW models' slice tables; new log-weights                                        [2]
+// = 12 + 4 K launches (44 at K = 8) where round 5 had ~130, no host synchronisation until the results are read back.
+static int mix_em_step_multi(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppca_model *const *models_in,
+                             const double *log_weights_in, int32_t nm, const ppca_prior *prior, ppca_model *const *models_out,
+                             double *log_weights_out, double *llk_in) {
+    const int64_t n = ds->n;
+    const int d = ds->d, k = models_in[0]->k;
+    const StatsLayout L(d, k);
+    const int64_t len = L.len, sums_at = (int64_t)nm * len, llk_at = sums_at + nm, total = llk_at + 1;
+    const int grid = fused_grid(n, ctx->n_cu), nb = select_blocks(n);
+    MixAux ax;
+    if (int rc = mix_aux(ctx, nm, ax)) return rc;
+    // every device block of the step is taken here, before the first collective (see mix_em_step)
+    const size_t errb_doubles = ((size_t)grid + 1) * W_GUARD_NCOL + (size_t)grid;  // bounds, their sums, 2 x grid ints
+    if (int rc = ensure(ctx->mixpack, ctx->mixpack_cap, sizeof(double) * (size_t)total)) return rc;
+    if (int rc = ensure(ctx->mix[0], ctx->mix_cap[0], sizeof(double) * (size_t)nm * n)) return rc;
+    if (int rc = ensure(ctx->mix[1], ctx->mix_cap[1], sizeof(double) * (size_t)nm * n)) return rc;
+    if (int rc = ensure(ctx->mix[2], ctx->mix_cap[2], sizeof(double) * (size_t)n)) return rc;
+    if (int rc = ensure(ctx->mix[4], ctx->mix_cap[4], sizeof(double) * (size_t)nm * n)) return rc;
+    if (int rc = ensure(ctx->mix[5], ctx->mix_cap[5], sizeof(int) * (size_t)nm * n)) return rc;
+    if (int rc = ensure(ctx->mix[6], ctx->mix_cap[6], sizeof(int) * (size_t)nm * ((size_t)nb + 1))) return rc;
+    if (int rc = ensure(ctx->mixred, ctx->mixred_cap, sizeof(double) * (size_t)(2 * nm + 1) * nb)) return rc;
+    if (int rc = ensure(ctx->part, ctx->part_cap, sizeof(double) * (size_t)(nm + 1) * grid * len)) return rc;
+    if (int rc = ensure(ctx->errb, ctx->errb_cap, sizeof(double) * errb_doubles * nm)) return rc;
+    if (int rc = ensure_hstage(ctx, sizeof(double) * ax.P + sizeof(int) * (size_t)nm)) return rc;
+    void *tab[MIX_MAX];
+    if (int rc = mix_tables(ctx, models_in, nm, tab)) return rc;
+    double *pack = static_cast<double *>(ctx->mixpack->p);
+    double *llk = static_cast<double *>(ctx->mix[0]->p), *u = static_cast<double *>(ctx->mix[1]->p), *lse = static_cast<double *>(ctx->mix[2]->p);
+    double *wsel = static_cast<double *>(ctx->mix[4]->p);
+    int *rows = static_cast<int *>(ctx->mix[5]->p), *counts = static_cast<int *>(ctx->mix[6]->p);
+    double *bpart = static_cast<double *>(ctx->mixred->p), *wpart = bpart + (size_t)(nm + 1) * nb;
+    double *part = static_cast<double *>(ctx->part->p), *part2 = part + (size_t)nm * grid * len;
+    double *aux = ax.shift;  // maxima -> shifts
+    // 1. responsibilities
+    if (int rc = mix_llk_sweeps_multi(ctx, ds, models_in, nm, llk, tab)) return rc;
+    if (int rc = mix_upload_logw(ctx, log_weights_in, nm, ax)) return rc;
+    HIP_TRY(launch_mix_posteriors2(llk, ax.logw, ds->w, n, nm, u, lse, bpart, ctx->stream));
+    HIP_TRY(launch_mix_stage2(bpart, n, nm, aux, pack + llk_at, ctx->stream));
+    if (comm) {
+        if (int rc = ppca_comm_allreduce(comm, aux, nm, 1)) return rc;
+    }
+    HIP_TRY(launch_mix_shift(aux, nm, ctx->stream));
+    // 2. the rows each component keeps, their weights, the weight sums
+    HIP_TRY(launch_select_multi(u, aux, n, nm, counts, rows, wsel, wpart, pack + sums_at, ax.used, ctx->stream));
+    // 3. the gathered component passes
+    ctx->stats_llk_at = -1;
+    PassArgs pa[MIX_MAX];
+    MixReduceArgs r{};
+    r.nm = nm;
+    r.len = len;
+    for (int c = 0; c < nm; ++c) {
+        PassArgs &a = pa[c];
+        a = PassArgs{};
+        a.X = ds->X;
+        a.ldx = d;
+        a.w = wsel + (size_t)c * n;
+        a.rows = rows + (size_t)c * n;
+        a.n = n;
+        a.n_dev = counts + (size_t)c * (nb + 1) + nb;
+        a.d = d;
+        a.model = models_in[c]->p();
+        a.part = part + (size_t)c * grid * len;
+        a.no_llk = 1;  // (the component passes' own llk is never read)
+        fused_qtab_layout(tab[c], a);
+        a.skip_qprep = 1;
+        a.errb = static_cast<double *>(ctx->errb->p) + errb_doubles * c;
+        GuardArgs &g = r.g[c];
+        g.errb = a.errb;
+        g.es = a.errb + (size_t)grid * W_GUARD_NCOL;
+        g.qflag = a.qflag;
+        g.wgflag = reinterpret_cast<int *>(g.es + W_GUARD_NCOL);
+        g.who = g.wgflag + grid;
+        g.n = a.n;
+        g.n_dev = a.n_dev;
+        g.d = d;
+        g.grid = grid;
+        r.part[c] = a.part;
+        r.out[c] = pack + (size_t)c * len;
+        HIP_TRY(launch_pass_em(k, grid, a, ctx->stream));
+    }
+    // 4. reductions + verdicts in one launch, then the (normally idle) second stages
+    HIP_TRY(launch_reduce_wguard_multi(k, r, grid, ctx->stream));
+    for (int c = 0; c < nm; ++c)
+        HIP_TRY(launch_em_fallback(k, grid, pa[c], r.g[c], r.part[c], part2, len, r.out[c], ctx->stream));
+    if (comm) {
+        if (int rc = ppca_comm_allreduce(comm, pack, total, 0)) return rc;
+    }
+    // 5. finalisations + the new models' tables (slot c is models_out[c]'s from here on), new log-weights
+    MixFinalArgs f{};
+    f.d = d;
+    f.nm = nm;
+    f.tau = prior ? prior->transformation_precision : 0.0;
+    f.has_ig = prior ? prior->has_isotropic_noise_prior : 0;
+    f.alpha = f.has_ig ? prior->isotropic_noise_alpha : 0.0;
+    f.beta = f.has_ig ? prior->isotropic_noise_beta : 0.0;
+    for (int c = 0; c < nm; ++c) {
+        touch(models_out[c]);
+        f.stats[c] = pack + (size_t)c * len;
+        f.min[c] = models_in[c]->p();
+        f.mout[c] = models_out[c]->p();
+        f.tab[c] = tab[c];
+    }
+    HIP_TRY(launch_finalize_qprep_multi(k, f, ctx->stream));
+    for (int c = 0; c < nm; ++c) ctx->mixq_slots[c] = std::make_pair((const void *)models_out[c]->buf->p, models_out[c]->stamp);
+    HIP_TRY(launch_mix_logweights(pack + sums_at, aux, pack + llk_at, nm, ax.out, ctx->stream));
+    double *hs = static_cast<double *>(ctx->hstage);
+    HIP_TRY(hipMemcpyAsync(hs, ax.out, sizeof(double) * (size_t)(nm + 1), hipMemcpyDeviceToHost, ctx->stream));
+    int *hused = reinterpret_cast<int *>(hs + ax.P);
+    HIP_TRY(hipMemcpyAsync(hused, ax.used, sizeof(int) * (size_t)nm, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < nm; ++c) log_weights_out[c] = hs[c];
+    if (llk_in) *llk_in = hs[nm];
+    ctx->mix_rows_used.assign(nm, 0);
+    for (int c = 0; c < nm; ++c) ctx->mix_rows_used[c] = (int64_t)hused[c];
+    return PPCA_OK;
+}
+
 int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppca_model *const *models_in,
                            const double *log_weights_in, int32_t nm, const ppca_prior *prior, ppca_model *const *models_out,
                            double *log_weights_out, double *llk_in) {
@@ -1443,6 +1660,14 @@ int ppca_host::mix_em_step(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, ppc
             return fail(PPCA_ERR_INVALID, "out may not alias model_in (component %d)", c);
     }
     if (int rc = check_prior(prior)) return rc;
+    if (!(prior && prior->has_mean_prior) && mix_multi_ok(ds, models_in, nm)) {
+        bool distinct = true;  // (the K output buffers are written by ONE launch: they must be K different ones)
+        for (int c = 0; c < nm && distinct; ++c)
+            for (int e = 0; e < nm; ++e)
+                if ((e != c && models_out[e]->buf == models_out[c]->buf) || models_out[c]->buf == models_in[e]->buf) distinct = false;
+        if (distinct)
+            return mix_em_step_multi(ctx, comm, ds, models_in, log_weights_in, nm, prior, models_out, log_weights_out, llk_in);
+    }
     // packed buffer: [statistics of component 0 | ... | nm weight sums | llk]; components may differ in state size
     std::vector<int64_t> off(nm + 1, 0);
     for (int c = 0; c < nm; ++c) off[c + 1] = off[c] + StatsLayout(models_in[c]->d, models_in[c]->k).len;

@@ -252,5 +252,16 @@ __device__ __forceinline__ double lean_log(double x) {
 template <int K>
 constexpr size_t qtab_bytes() { return (size_t)Cfg<K>::NTP * QS * 4 * 1024; }
 
+// One model's block of fused_qtab_bytes(): [64 scales | 8 doubles of guard words | digit table (sized for k = FUSED_MAX_K) | zero-padded
+// C | C in em9_kernel's operand order].  The host's fused_qtab_layout and the multi-component kernels (one block per mixture
+// component, MixLlkArgs::tab) point a PassArgs at it with this.
+__host__ __device__ inline void fused_qtab_view(void *base, PassArgs &a) {
+    a.qscale = static_cast<double *>(base);
+    a.qflag = reinterpret_cast<int *>(a.qscale + 64);
+    a.qtab = reinterpret_cast<signed char *>(a.qscale + 72);
+    a.cpad = reinterpret_cast<const double *>(a.qtab + qtab_bytes<FUSED_MAX_K>());  // (behind the largest table)
+    a.cpb = a.cpad + FUSED_MAX_D * (FUSED_MAX_K + 1);
+}
+
 
 }  // namespace ppca

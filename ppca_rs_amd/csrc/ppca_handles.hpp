@@ -87,6 +87,17 @@ struct ppca_ctx {
     size_t mixpack_cap = 0;
     BufRef mixaux;   // ... its small device-side vectors: maxima / shifts, new log-weights + llk
     size_t mixaux_cap = 0;
+    // The multi-component form of the mixture step (round 6; components of one state size on the fused path, <= MIX_MAX of them): one
+    // slice-table block per component (mixq: nm x mixq_stride bytes; slot c holds the table of the model content mixq_slots[c] =
+    // (device buffer, write stamp): written by qprep_multi_kernel, or by the step's finalisation for the NEXT iteration), the per-block
+    // partials of the responsibilities' maxima / llk and of the weight sums (mixred), per-component row lists / weights / counts
+    // (mix[4..6] sized nm x) and per-component partial statistics (part sized nm + 1 x).
+    BufRef mixq;
+    size_t mixq_cap = 0, mixq_stride = 0;
+    const void *mixq_base = nullptr;
+    std::vector<std::pair<const void *, uint64_t>> mixq_slots;
+    BufRef mixred;
+    size_t mixred_cap = 0;
     std::vector<int64_t> mix_rows_used;  // rows of this context's shard each component pass of the last mixture step gathered
     // pinned host memory: a small staging area for asynchronous uploads / downloads of a few values, and the two chunk
     // buffers of the pipelined device-to-host copy (ppca_dataset_to_host, ppca_infer); allocated on first use

@@ -78,6 +78,41 @@ struct GuardArgs {
     int d;
     int grid;             // workgroups of the guarded launch (= partials)
 };
+// Multi-component launches of the mixture step (round 6): the per-component pointers travel BY VALUE in the kernel arguments, so a
+// launch covers at most MIX_MAX components (larger mixtures, or components of different state sizes, run component by component).
+constexpr int MIX_MAX = 16;
+struct MixLlkArgs {  // mix_llk8_kernel (ppca_llk.hip): the llk sweeps of all components in one launch
+    const double *X;
+    int64_t ldx, n;
+    int d, nm;
+    int runs_per_xcd;             // mix_llk_runs_per_xcd(grid, nm)
+    const double *model[MIX_MAX];
+    void *tab[MIX_MAX];           // the component's slice-table block (fused_qtab_view)
+    double *llks[MIX_MAX];        // n per component
+};
+struct MixTabArgs {  // qprep_multi_kernel: slice tables + guard flags + padded C of nm models in one launch
+    int d, nm;
+    const double *model[MIX_MAX];
+    void *tab[MIX_MAX];
+};
+struct MixFinalArgs {  // finalize_qprep_multi_kernel: the M-step finalisation of nm components + the new models' tables
+    int d, nm;
+    double tau;
+    int has_ig;
+    double alpha, beta;
+    const double *stats[MIX_MAX];
+    const double *min[MIX_MAX];
+    double *mout[MIX_MAX];
+    void *tab[MIX_MAX];
+};
+struct MixReduceArgs {  // reduce_wguard_multi_kernel: reduction + verdict of nm guarded EM passes in one launch
+    int nm;
+    int64_t len;
+    const double *part[MIX_MAX];
+    double *out[MIX_MAX];
+    GuardArgs g[MIX_MAX];
+};
+
 // em9_kernel's b = X~ C on v_mfma_f64_4x4x4 (round 5): one instruction = four blocks = (two
 // 4-dim groups kb) x (two 4-sample groups sb); its A operand is C^T: lane 16 k + 8 kb + 4 sb + i holds C[dim][4 c + i] with
 // dim = 128 kq + 32 (q >> 2) + 16 kb + 4 (q & 3) + k for the wave's dimension half kq, step q = 0..15 and column group c -- the same
@@ -137,6 +172,18 @@ hipError_t launch_em16(int k, int grid, const Em16Launch &a, hipStream_t s);
 // The log-likelihood sweep alone (ppca_llk.hip): per-sample llks (nullable) and the per-workgroup scalars; honours
 // a.qflag like the int8 instantiation of pass_kernel.
 hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s);
+// ... of ALL components of a mixture in one launch (same state size k <= FUSED_MAX_K, nm <= MIX_MAX): units = (component, run of
+// tiles), dealt so that the workgroups of one XCD walk the same rows for the different components (X from HBM once per iteration)
+bool mix_llk8_available();  // false under PPCA_LLK8=0
+int mix_llk_runs_per_xcd(int grid, int nm);
+hipError_t launch_mix_llk8(int k, int grid, const MixLlkArgs &a, hipStream_t s);
+// the fp64-Gram instantiation of the post pass alone, behind a.qflag (the fallback of the int8 llk sweeps: returns at once unless the
+// model's table tripped the dynamic-range guard)
+hipError_t launch_pass_post_fp64(int k, int grid, const PassArgs &a, hipStream_t s);
+int fused_gram_mode();  // 0: int8 behind the guard (default); 1: fp64 pinned (PPCA_GRAM_FP64=1); 2: int8 without guard (tuning builds)
+hipError_t launch_qprep_multi(int k, const MixTabArgs &a, hipStream_t s);
+hipError_t launch_finalize_qprep_multi(int k, const MixFinalArgs &a, hipStream_t s);
+hipError_t launch_reduce_wguard_multi(int k, const MixReduceArgs &a, int grid_parts, hipStream_t s);
 hipError_t launch_reduce_partials(const double *part, int grid_parts, int64_t len, double *out, hipStream_t s, int accumulate = 0,
                                   const int *run_if = nullptr);  // run_if: device flag; the kernel returns at once when it is 0
 // A guarded EM pass of the fused path after launch_pass_em, in two launches (round 5; rounds 3-4: reduction, wguard_kernel,
@@ -205,5 +252,17 @@ hipError_t launch_mix_logweights(const double *sums, const double *shift, const 
 hipError_t launch_select_positive(const double *v, const double *shift_dev, int64_t n, int *counts, int *rows, double *wout,
                                   hipStream_t s);
 int select_blocks(int64_t n);
+// The same for nm components at once (one launch per stage instead of one per component and stage):
+//   launch_mix_posteriors2   u, lse as launch_mix_posteriors + per-block partials bpart[nm + 1][select_blocks(n)]: the block maxima of
+//                            u_c (NaNs skipped) and the block sums of w_i lse_i; launch_mix_stage2 reduces them in a fixed order into
+//                            maxima[nm] and *llk_out.
+//   launch_select_multi      counts[nm][nb + 1] (-> exclusive offsets, total at [nb]), rows[nm][n], wout[nm][n] as
+//                            launch_select_positive per component, and the sums of the kept weights into sums_out[nm], the row
+//                            counts into used_out[nm] (fixed order: per-block sums in wpart[nm][nb], then one workgroup per component).
+hipError_t launch_mix_posteriors2(const double *llk, const double *logw_dev, const double *w, int64_t n, int nm, double *u, double *lse,
+                                  double *bpart, hipStream_t s);
+hipError_t launch_mix_stage2(const double *bpart, int64_t n, int nm, double *maxima, double *llk_out, hipStream_t s);
+hipError_t launch_select_multi(const double *u, const double *shift_dev, int64_t n, int nm, int *counts, int *rows, double *wout, double *wpart,
+                               double *sums_out, int *used_out, hipStream_t s);
 
 }  // namespace ppca

@@ -203,6 +203,15 @@ template <int K>
 __global__ __launch_bounds__(256) void qprep_kernel(const double *model, int d, double *qscale, signed char *qtab, int *qflag) {
     qprep_body<K>([=](int j, int a) { return model[MODEL_HDR + (int64_t)j * K + a]; }, model[1], d, qscale, qtab, qflag);
 }
+// ... of several models in one launch (the components of a mixture): grid (tiles, models), each model's block of fused_qtab_bytes()
+template <int K>
+__global__ __launch_bounds__(256) void qprep_multi_kernel(MixTabArgs m) {
+    const int c = blockIdx.y;
+    const double *model = m.model[c];
+    PassArgs t{};
+    fused_qtab_view(m.tab[c], t);
+    qprep_body<K>([=](int j, int a) { return model[MODEL_HDR + (int64_t)j * K + a]; }, model[1], m.d, t.qscale, t.qtab, t.qflag);
+}
 
 // NW = waves per workgroup: 4 (one wave per SIMD, 512 registers each) or 8 (two waves per SIMD,
 // 256 registers each, every wave owning half as many accumulator tiles).
@@ -1384,10 +1393,10 @@ constexpr double WGUARD_TOL = 5.820766091346741e-11;  // 2^-34
 //
 // One launch does the reduction AND the verdict: workgroups [0, ceil(len / 64)) sum the statistics (out[e] = the fixed order of
 // reduce_partials_kernel, bit-identical to it), two more sum the columns of the bounds; every workgroup takes a ticket after
-// its sums are visible (the storing wave's __threadfence: the release; the atomic; __threadfence in the last one: the acquire
-// -- a CU's L1 is never refreshed by another CU's stores), the holder of the last ticket runs the check.
+// its sums have left (sc1 stores drained by an explicit s_waitcnt vmcnt(0) in the storing wave, then the workgroup barrier, then
+// the ticket atomic; the last workgroup reads them back with sc1 loads), the holder of the last ticket runs the check.
 template <int K>
-__global__ __launch_bounds__(256) void reduce_wguard_kernel(const double *part, int64_t len, double *out, GuardArgs g) {
+__device__ __forceinline__ void reduce_wguard_body(const double *part, int64_t len, double *out, const GuardArgs &g) {
     constexpr int KP = Cfg<K>::KP, NTP = Cfg<K>::NTP;
     __shared__ double red[4][64];
     __shared__ int last_s;
@@ -1434,7 +1443,9 @@ __global__ __launch_bounds__(256) void reduce_wguard_kernel(const double *part, 
             // drained by the storing wave before the ticket, and every load of them below is an sc1 load (served past the L1 and
             // the reader's own L2) -- the form MI355X_MICROARCH.md lists as valid in place of the fences.
             if (e < elen) __hip_atomic_store((bounds ? g.es : out) + e, (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (s_waitcnt vmcnt(0): the stores have left)
+            // The drain is written out: a workgroup-scope release fence emits NO s_waitcnt vmcnt on gfx950 (advisor, round 5: the built
+            // code object had store -> s_barrier -> ticket atomic, nothing ordering the sc1 store's completion before the ticket).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();
@@ -1541,6 +1552,17 @@ __global__ __launch_bounds__(256) void reduce_wguard_kernel(const double *part, 
     }
     __syncthreads();
     finish(2, 1, nflag, nflag_s);
+}
+template <int K>
+__global__ __launch_bounds__(256) void reduce_wguard_kernel(const double *part, int64_t len, double *out, GuardArgs g) {
+    reduce_wguard_body<K>(part, len, out, g);
+}
+// ... of the nm guarded component passes of a mixture step in one launch: grid (blocks, components); every component has its own
+// partials, bounds, guard words (ticket counter included) and verdict
+template <int K>
+__global__ __launch_bounds__(256) void reduce_wguard_multi_kernel(MixReduceArgs m) {
+    const int c = blockIdx.y;
+    reduce_wguard_body<K>(m.part[c], m.len, m.out[c], m.g[c]);
 }
 
 // Second reduction of a guarded EM pass (behind the mode flag): the un-flagged workgroups' partials of the int8 kernel + the
@@ -1676,6 +1698,18 @@ __global__ __launch_bounds__(256) void finalize_qprep_kernel(const double *stats
     __syncthreads();
     qprep_body<K>([&](int j, int a) { return cn[j * K + a]; }, s2n, d, qscale, qtab, qflag);
 }
+// ... of the nm components of a mixture step in one launch: grid (tiles, components)
+template <int K>
+__global__ __launch_bounds__(256) void finalize_qprep_multi_kernel(MixFinalArgs m) {
+    __shared__ double cn[FUSED_MAX_D * K];
+    __shared__ double s2n;
+    const int c = blockIdx.y;
+    finalize_body<K>(m.stats[c], m.min[c], m.mout[c], m.d, m.tau, m.has_ig, m.alpha, m.beta, blockIdx.x == 0, cn, &s2n);
+    __syncthreads();
+    PassArgs t{};
+    fused_qtab_view(m.tab[c], t);
+    qprep_body<K>([&](int j, int a) { return cn[j * K + a]; }, s2n, m.d, t.qscale, t.qtab, t.qflag);
+}
 
 // ------------------------------------------------------------------ synthetic data
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
@@ -1801,6 +1835,78 @@ __global__ void mix_posteriors_kernel(const double *llk, const double *logw, con
     }
 }
 
+// The same + what the mixture step needs of u and lse afterwards, so that no further sweep over them is launched: per block of 256
+// samples the maxima of u_c (NaNs skipped, mix.rs:312-315) and the sum of w_i lse_i, into bpart[nm + 1][gridDim.x] (fixed order: lane
+// butterflies, then the four waves in index order).  nm <= MIX_MAX.
+__global__ __launch_bounds__(256) void mix_posteriors2_kernel(const double *llk, const double *logw, const double *w, int64_t n, int nm,
+                                                               double *u, double *lse, double *bpart) {
+    __shared__ double red[4][MIX_MAX + 1];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < n;
+    double lv[MIX_MAX], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MIX_MAX; ++c) {
+        lv[c] = (in && c < nm) ? llk[(int64_t)c * n + i] + logw[c] : -INFINITY;
+        if (c < nm) mx = fmax(mx, lv[c]);
+    }
+    double sm = 0.0;
+#pragma unroll
+    for (int c = 0; c < MIX_MAX; ++c)
+        if (c < nm) sm += exp(lv[c] - mx);
+    const double ln = log(sm);
+    const double wi = in ? (w ? w[i] : 1.0) : 0.0;
+    const double lw = wi > 0.0 ? log(wi) : -INFINITY;
+    if (in) lse[i] = mx + ln;
+    double part = in ? (w ? (mx + ln) * wi : mx + ln) : 0.0;  // (launch_reduce_sum's term: v w or v)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) red[wave][MIX_MAX] = part;
+#pragma unroll
+    for (int c = 0; c < MIX_MAX; ++c) {
+        if (c < nm) {
+            double uc = -INFINITY;
+            if (in) {
+                const double v = lw + (lv[c] - mx - ln);
+                u[(int64_t)c * n + i] = v;
+                uc = (v == v) ? v : -INFINITY;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) uc = fmax(uc, __shfl_xor(uc, o, 64));
+            if (lane == 0) red[wave][c] = uc;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nm) {
+        const int c = threadIdx.x;
+        bpart[(int64_t)c * gridDim.x + blockIdx.x] = fmax(fmax(red[0][c], red[1][c]), fmax(red[2][c], red[3][c]));
+    } else if (threadIdx.x == MIX_MAX) {
+        bpart[(int64_t)nm * gridDim.x + blockIdx.x] = (red[0][MIX_MAX] + red[1][MIX_MAX]) + (red[2][MIX_MAX] + red[3][MIX_MAX]);
+    }
+}
+// Second stage: workgroup c < nm: maxima[c] = max of bpart[c][0 .. nb); workgroup nm: *llk_out = sum of bpart[nm][0 .. nb) -- thread t
+// takes the blocks t, t + 256, ... in order, then a fixed tree.
+__global__ __launch_bounds__(256) void mix_stage2_kernel(const double *bpart, int nb, int nm, double *maxima, double *llk_out) {
+    __shared__ double red[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const bool is_max = c < nm;
+    double acc = is_max ? -INFINITY : 0.0;
+    for (int b = t; b < nb; b += 256) {
+        const double v = bpart[(int64_t)c * nb + b];
+        acc = is_max ? fmax(acc, v) : acc + v;
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] = is_max ? fmax(red[t], red[t + o]) : red[t] + red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (is_max) maxima[c] = red[0];
+        else *llk_out = red[0];
+    }
+}
+
 template <bool MAX>
 __global__ void reduce_stage_kernel(const double *v, const double *w, int64_t n, double *out, const int *n_dev = nullptr) {
     __shared__ double red[256];
@@ -1901,6 +2007,108 @@ hipError_t launch_select_positive(const double *v, const double *shift_dev, int6
 }
 int select_blocks(int64_t n) { return (int)((n + SEL_BLOCK - 1) / SEL_BLOCK); }
 
+// The three selection steps for nm components at once (blockIdx.y = component; component c's arrays at c * n, its counts at
+// c * (nb + 1)), the scatter also leaving the block's sum of kept weights (fixed order), and a last step that sums those per component.
+__global__ __launch_bounds__(SEL_BLOCK) void select_count_multi_kernel(const double *u, const double *shift, int64_t n, int nb, int *counts) {
+    const int c = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * SEL_BLOCK + threadIdx.x;
+    const bool keep = i < n && exp(u[(int64_t)c * n + i] - shift[c]) > SEL_MIN_WEIGHT;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    __shared__ int wc[SEL_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(int64_t)c * (nb + 1) + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+__global__ __launch_bounds__(1024) void select_scan_multi_kernel(int *counts_all, int nblocks) {
+    int *counts = counts_all + (int64_t)blockIdx.x * (nblocks + 1);
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = t * per, b1 = (b0 + per < nblocks) ? b0 + per : nblocks;
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += counts[b];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int add = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int b = b0; b < b1; ++b) {
+        const int c = counts[b];
+        counts[b] = run;
+        run += c;
+    }
+    if (t == 1023) counts[nblocks] = part[1023];
+}
+__global__ __launch_bounds__(SEL_BLOCK) void select_scatter_multi_kernel(const double *u, const double *shift, int64_t n, int nb, const int *counts,
+                                                                          int *rows, double *wout, double *wpart) {
+    const int c = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * SEL_BLOCK + threadIdx.x;
+    const double w = i < n ? exp(u[(int64_t)c * n + i] - shift[c]) : 0.0;
+    const bool keep = w > SEL_MIN_WEIGHT;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    __shared__ int wc[SEL_BLOCK / 64];
+    __shared__ double ws[SEL_BLOCK / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double sw = keep ? w : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sw += __shfl_xor(sw, o, 64);
+    if (lane == 0) {
+        wc[wave] = __popcll(bal);
+        ws[wave] = sw;
+    }
+    __syncthreads();
+    int base = counts[(int64_t)c * (nb + 1) + blockIdx.x];
+    for (int q = 0; q < wave; ++q) base += wc[q];
+    if (keep) {
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        rows[(int64_t)c * n + pos] = (int)i;
+        wout[(int64_t)c * n + pos] = w;
+    }
+    if (threadIdx.x == 0) wpart[(int64_t)c * nb + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+__global__ __launch_bounds__(256) void mix_wsum_kernel(const double *wpart, int nb, const int *counts, double *sums_out, int *used_out) {
+    __shared__ double red[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double acc = 0.0;
+    for (int b = t; b < nb; b += 256) acc += wpart[(int64_t)c * nb + b];
+    red[t] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        sums_out[c] = red[0];
+        used_out[c] = counts[(int64_t)c * (nb + 1) + nb];
+    }
+}
+hipError_t launch_select_multi(const double *u, const double *shift_dev, int64_t n, int nm, int *counts, int *rows, double *wout, double *wpart,
+                               double *sums_out, int *used_out, hipStream_t s) {
+    if (n <= 0 || nm <= 0) return hipSuccess;
+    const int nb = (int)((n + SEL_BLOCK - 1) / SEL_BLOCK);
+    hipLaunchKernelGGL(select_count_multi_kernel, dim3(nb, nm), dim3(SEL_BLOCK), 0, s, u, shift_dev, n, nb, counts);
+    hipLaunchKernelGGL(select_scan_multi_kernel, dim3(nm), dim3(1024), 0, s, counts, nb);
+    hipLaunchKernelGGL(select_scatter_multi_kernel, dim3(nb, nm), dim3(SEL_BLOCK), 0, s, u, shift_dev, n, nb, (const int *)counts, rows, wout, wpart);
+    hipLaunchKernelGGL(mix_wsum_kernel, dim3(nm), dim3(256), 0, s, (const double *)wpart, nb, (const int *)counts, sums_out, used_out);
+    return hipGetLastError();
+}
+hipError_t launch_mix_posteriors2(const double *llk, const double *logw_dev, const double *w, int64_t n, int nm, double *u, double *lse,
+                                  double *bpart, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (nm > MIX_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mix_posteriors2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, llk, logw_dev, w, n, nm, u, lse, bpart);
+    return hipGetLastError();
+}
+hipError_t launch_mix_stage2(const double *bpart, int64_t n, int nm, double *maxima, double *llk_out, hipStream_t s) {
+    const int nb = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(mix_stage2_kernel, dim3(nm + 1), dim3(256), 0, s, bpart, nb, nm, maxima, llk_out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launchers
 int fused_grid(int64_t n, int n_cu) {
     int64_t tiles = (n + FUSED_TILE - 1) / FUSED_TILE;
@@ -1944,13 +2152,7 @@ static hipError_t launch_pass_t(int grid, const PassArgs &a, hipStream_t s) {
 }
 
 size_t fused_qtab_bytes() { return qtab_bytes<FUSED_MAX_K>() + (72 + FUSED_MAX_D * (FUSED_MAX_K + 1) + CPB_DOUBLES) * sizeof(double); }
-void fused_qtab_layout(void *base, PassArgs &a) {  // [64 scales | 8 doubles of guard flags | digit table]
-    a.qscale = static_cast<double *>(base);
-    a.qflag = reinterpret_cast<int *>(a.qscale + 64);
-    a.qtab = reinterpret_cast<signed char *>(a.qscale + 72);
-    a.cpad = reinterpret_cast<const double *>(a.qtab + qtab_bytes<FUSED_MAX_K>());  // (behind the largest table)
-    a.cpb = a.cpad + FUSED_MAX_D * (FUSED_MAX_K + 1);
-}
+void fused_qtab_layout(void *base, PassArgs &a) { fused_qtab_view(base, a); }  // [64 scales | 8 doubles of guard flags | digit table | ...]
 
 // Gram engine of the fused passes: 0 = int8-sliced MFMA behind the dynamic-range guard, with the fp64-MFMA instantiation
 // as its on-device fallback (default); 1 = fp64 MFMA always (PPCA_GRAM_FP64=1: a safe choice, so a run-time switch);
@@ -2096,6 +2298,43 @@ hipError_t launch_em_fallback(int k, int grid, PassArgs a, const GuardArgs &g, c
     const int blocks = (int)((len + 63) / 64);
     hipLaunchKernelGGL(reduce_fallback_kernel, dim3(blocks), dim3(256), 0, s, part, (const double *)part2, (const int *)g.wgflag, grid, len, stats,
                        (const int *)(g.qflag + QF_MODE));
+    return hipGetLastError();
+#endif
+}
+
+int fused_gram_mode() {
+#ifdef PPCA_DEV_K10
+    return 2;
+#else
+    return gram_mode();
+#endif
+}
+hipError_t launch_pass_post_fp64(int k, int grid, const PassArgs &a, hipStream_t s) {
+#ifdef PPCA_DEV_K10
+    return hipSuccess;
+#else
+    PPCA_DISPATCH_K(k, return (launch_pass_t<KK, false, 4, false>(grid, a, s)));
+    return hipErrorInvalidValue;
+#endif
+}
+hipError_t launch_qprep_multi(int k, const MixTabArgs &a, hipStream_t s) {
+    PPCA_DISPATCH_K(k, hipLaunchKernelGGL((qprep_multi_kernel<KK>), dim3(Cfg<KK>::NTP, a.nm), dim3(256), 0, s, a));
+    return hipGetLastError();
+}
+hipError_t launch_finalize_qprep_multi(int k, const MixFinalArgs &a, hipStream_t s) {
+    PPCA_DISPATCH_K(k, hipLaunchKernelGGL((finalize_qprep_multi_kernel<KK>), dim3(Cfg<KK>::NTP, a.nm), dim3(256), 0, s, a));
+    return hipGetLastError();
+}
+hipError_t launch_reduce_wguard_multi(int k, const MixReduceArgs &a, int grid_parts, hipStream_t s) {
+#ifdef PPCA_DEV_K10
+    return hipErrorInvalidValue;
+#else
+    (void)grid_parts;
+    MixReduceArgs h = a;
+    if (!(em8_enabled() && em8_covers(k)))
+        for (int c = 0; c < h.nm; ++c) h.g[c].errb = nullptr;  // (only em8_kernel / em9_kernel cut their rows)
+    const int blocks = (int)((a.len + 63) / 64) + (W_GUARD_NCOL + 63) / 64;
+    PPCA_DISPATCH_K(k, hipLaunchKernelGGL((reduce_wguard_multi_kernel<KK>), dim3(blocks, a.nm), dim3(256), 0, s, h));
     return hipGetLastError();
 #endif
 }

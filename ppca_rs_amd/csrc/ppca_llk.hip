@@ -368,13 +368,14 @@ __device__ __forceinline__ void store_row_sums4(const double (&pxx)[4], int lane
     }
 }
 
+// The sweep over the tiles [tile_begin, tile_end) of p's rows by ONE workgroup (the body of llk8_kernel; mix_llk8_kernel below walks
+// several (model, run of tiles) units with it).  scal: where the workgroup's scalars go (nullable).
 template <int K>
-__global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
+__device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const int64_t tile_begin, const int64_t tile_end, double *scal) {
     using cfg = CfgL8<K>;
     constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS, BS = cfg::BS;
     constexpr int NW = 8, RPW = B / NW, DPQ = cfg::DP / 4, STEPS = DPQ / 4;
     static_assert(NTP <= 4 && QS == 8 && RPW == 4, "int8 Gram: (column tile, row tile) wave units, 8 digit slices; 4 rows per wave");
-    extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Xs = sm + cfg::OFF_X;
     double *Cs = sm + cfg::OFF_C;
     double *Gs = sm + cfg::OFF_G;
@@ -382,12 +383,6 @@ __global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
     unsigned long long *Ms = reinterpret_cast<unsigned long long *>(sm + cfg::OFF_M);
     double *xxs = sm + cfg::OFF_XX;
 
-    if (p.qflag) {  // qprep's dynamic-range guard: pass_kernel<K, false, 4, false> runs instead
-        int unsafe = 0;
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) unsafe |= p.qflag[t];
-        if (unsafe) return;
-    }
     const int tid = threadIdx.x, lane_entry = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int d = p.d;
@@ -401,10 +396,6 @@ __global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
     }
     for (int idx = tid; idx < cfg::DP; idx += 512) sm[cfg::OFF_MU + idx] = idx < d ? mMean[idx] : 0.0;
 
-    const int64_t ntiles = (n + B - 1) / B;
-    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
-    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
     const int64_t nleft = n - tile_begin * B;
     const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));
     const double *Xwg = p.X + tile_begin * B * p.ldx;
@@ -613,10 +604,10 @@ __global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
         }
         __syncthreads();
     }
-    if (wave == 0) {
+    if (wave == 0 && scal) {
         const double v2 = wave_sum(run_llk), v3 = wave_sum(run_w);
         if (lane_entry == 0) {
-            double *sc = p.scal_part + (int64_t)blockIdx.x * 8;
+            double *sc = scal;
             sc[SC_SQERR] = 0.0;
             sc[SC_DEVSQ] = 0.0;
             sc[SC_LLK] = v2;
@@ -626,6 +617,66 @@ __global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
             sc[6] = 0.0;
             sc[7] = 0.0;
         }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (p.qflag) {  // qprep's dynamic-range guard: pass_kernel<K, false, 4, false> runs instead
+        int unsafe = 0;
+#pragma unroll
+        for (int t = 0; t < CfgL8<K>::NTP; ++t) unsafe |= p.qflag[t];
+        if (unsafe) return;
+    }
+    constexpr int B = CfgL8<K>::B;
+    const int64_t ntiles = (p.n + B - 1) / B;
+    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+    llk8_run<K>(p, sm, tile_begin, tile_end, p.scal_part + (int64_t)blockIdx.x * 8);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mix_llk8_kernel -- the log-likelihood sweeps of ALL components of a mixture in ONE launch (PPCAMix::llks / the responsibilities
+// of PPCAMix::iterate_with_prior, ppca/src/mix.rs:137-149, :283-288: llks of every component over every sample).  Round 5 ran one
+// llk8_kernel launch per component: X came from HBM once per component (16.8 KB per sample and iteration at K = 8 against the 2.1 KB
+// of one read).  Here a unit of work is (component, run of tiles) and the units are dealt so that the workgroups of ONE XCD (the
+// blocks b with equal b mod 8 share an XCD's L2: observed placement, used for speed only) walk the SAME runs for the different
+// components at the same time: a tile comes from HBM once and from that XCD's L2 for the other components.  Per unit the kernel is
+// llk8_kernel's body (its component's C tile into LDS, its wave's slice of that component's digit table into registers), so the llks
+// are bit-identical to the per-component sweeps.  A component whose table tripped the dynamic-range guard is skipped here and served
+// by the fp64 instantiation of pass_kernel behind the same flag (launched per component by the host: returns at once otherwise).
+template <int K>
+__global__ __launch_bounds__(512) void mix_llk8_kernel(MixLlkArgs m) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int B = CfgL8<K>::B, NTP = CfgL8<K>::NTP;
+    const int W = gridDim.x, X = (W % 8 == 0) ? 8 : 1, Wx = W / X;
+    const int x = blockIdx.x % X, j = blockIdx.x / X;
+    const int64_t ntiles = (m.n + B - 1) / B;
+    const int R = X * m.runs_per_xcd;
+    int64_t tiles_per_run = (ntiles + R - 1) / R;
+    tiles_per_run += tiles_per_run & 1;  // (rounds are two tiles: an even run keeps every run's pairs those of its neighbours)
+    const int units = m.nm * m.runs_per_xcd;
+    for (int q = j; q < units; q += Wx) {
+        const int c = q % m.nm, run = x + X * (q / m.nm);
+        const int64_t tile_begin = (int64_t)run * tiles_per_run;
+        const int64_t tile_end = tile_begin + tiles_per_run < ntiles ? tile_begin + tiles_per_run : ntiles;
+        if (tile_begin >= tile_end) continue;
+        PassArgs p{};
+        p.X = m.X;
+        p.ldx = m.ldx;
+        p.n = m.n;
+        p.d = m.d;
+        p.model = m.model[c];
+        fused_qtab_view(m.tab[c], p);
+        p.llks = m.llks[c];
+        int unsafe = 0;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) unsafe |= p.qflag[t];
+        if (unsafe) continue;
+        __syncthreads();  // (the previous unit's readers of the C tile / mean are done)
+        llk8_run<K>(p, sm, tile_begin, tile_end, nullptr);
     }
 }
 
@@ -670,6 +721,58 @@ static hipError_t launch_llk2_t(int grid, const PassArgs &a, hipStream_t s) {
     }
     hipLaunchKernelGGL((llk2_kernel<K>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_mix_llk8_t(int grid, const MixLlkArgs &a, hipStream_t s) {
+    const size_t lds = sizeof(double) * CfgL8<K>::LDS_DOUBLES;
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mix_llk8_kernel<K>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((mix_llk8_kernel<K>), dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// Runs of tiles per XCD group of workgroups for a launch of `grid` workgroups over nm components: the smallest count that deals
+// every workgroup the same number of (component, run) units.
+int mix_llk_runs_per_xcd(int grid, int nm) {
+    const int X = (grid % 8 == 0) ? 8 : 1, Wx = grid / X;
+    int a = nm, b = Wx;
+    while (b) {
+        const int t = a % b;
+        a = b;
+        b = t;
+    }
+    return Wx / a;  // Wx / gcd(nm, Wx)
+}
+
+bool mix_llk8_available() { return llk8_enabled(); }
+
+hipError_t launch_mix_llk8(int k, int grid, const MixLlkArgs &a, hipStream_t s) {
+    switch (k) {
+#ifdef PPCA_DEV_K10
+        case 10: return launch_mix_llk8_t<10>(grid, a, s);
+#else
+        case 1: return launch_mix_llk8_t<1>(grid, a, s);
+        case 2: return launch_mix_llk8_t<2>(grid, a, s);
+        case 3: return launch_mix_llk8_t<3>(grid, a, s);
+        case 4: return launch_mix_llk8_t<4>(grid, a, s);
+        case 5: return launch_mix_llk8_t<5>(grid, a, s);
+        case 6: return launch_mix_llk8_t<6>(grid, a, s);
+        case 7: return launch_mix_llk8_t<7>(grid, a, s);
+        case 8: return launch_mix_llk8_t<8>(grid, a, s);
+        case 9: return launch_mix_llk8_t<9>(grid, a, s);
+        case 10: return launch_mix_llk8_t<10>(grid, a, s);
+#endif
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s) {

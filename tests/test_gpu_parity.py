@@ -1426,3 +1426,58 @@ def test_large_downloads_are_pipelined_and_canonical(P):
     part = m.infer(ds._slice(650_000, 1000))
     np.testing.assert_array_equal(inf.states()[650_000:651_000], part.states())
     np.testing.assert_array_equal(np.array(inf.covariances()[650_000:651_000]), np.array(part.covariances()))
+
+
+# --------------------------------------------------------------------------- round 6
+def test_multi_component_step_equals_component_by_component(oracle, tmp_path):
+    """Round 6: the mixture step launches every stage ONCE over all components (mix_llk8_kernel: the K llk sweeps with X read from
+    HBM once; selection, reduction + verdict, finalisation + next slice tables with blockIdx.y = component).  Against the
+    component-by-component form of rounds 2-5 (PPCA_MIX_MULTI=0) in a child process each: the llks are BIT-identical (same per-sample
+    arithmetic), and so are the new models (same row lists, weights and partial statistics per component); the log-weights and the
+    llk total differ only by the order of two sums.  The case with a component outside the int8 Gram's dynamic range must take that
+    component's llks from the fp64 instantiation (engine 1) and agree with the oracle."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"mix_multi_{flag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mix_multi_check.py"), path],
+                           capture_output=True, text=True, env=dict(os.environ, PPCA_MIX_MULTI=flag), timeout=900)
+        assert r.returncode == 0 and "mix multi check written" in r.stdout, (flag, r.stdout[-1500:], r.stderr[-2500:])
+        outs.append(np.load(path))
+    multi, single = outs
+    for case in ("k8", "k8_grid8", "k3_grid2", "k3_grid16", "k16"):
+        np.testing.assert_array_equal(multi[case + "_llks"], single[case + "_llks"], err_msg=case)
+        np.testing.assert_array_equal(multi[case + "_lp"], single[case + "_lp"], err_msg=case)
+        np.testing.assert_array_equal(multi[case + "_c"], single[case + "_c"], err_msg=case)
+        np.testing.assert_array_equal(multi[case + "_mean"], single[case + "_mean"], err_msg=case)
+        np.testing.assert_array_equal(multi[case + "_sigma"], single[case + "_sigma"], err_msg=case)
+        assert np.abs(multi[case + "_lw"] - single[case + "_lw"]).max() < 1e-12, case
+        assert _rel(multi[case + "_trace"], single[case + "_trace"]) < 1e-13, case
+    np.testing.assert_array_equal(multi["guard_llks"], single["guard_llks"])
+    np.testing.assert_array_equal(multi["guard_engine"], np.array([0, 0, 1, 0]))
+
+
+def test_multi_component_sweep_with_a_guard_tripping_component(P, oracle):
+    """mix_llk8_kernel skips a component whose slice table tripped the dynamic-range guard; the fp64 instantiation behind the same
+    flag serves it (mix.rs:137-149: llks of every component).  Against the oracle, with the tripping component in slot 2 of 4."""
+    rng = np.random.default_rng(811)
+    d, k, nm, n = 256, 10, 4, 900
+    big = np.sort(rng.choice(d, 200, replace=False))
+    scale = np.ones(d)
+    scale[big] = 1.0e8
+    sig = np.array([0.9, 1.1, 0.05, 1.0])
+    cs = rng.standard_normal((nm, d, k))
+    cs[2] *= scale[:, None]
+    ms = 0.1 * rng.standard_normal((nm, d))
+    lw = np.log(np.array([0.2, 0.3, 0.1, 0.4]))
+    x = rng.standard_normal((n, k)) @ rng.standard_normal((k, d)) + 0.3 * rng.standard_normal((n, d))
+    x[rng.random((n, d)) < 0.3] = np.nan
+    x[:, big] = np.nan
+    ds = P.Dataset(x)
+    mix = P.PPCAMix([P.PPCAModel(sig[c], cs[c], ms[c]) for c in range(nm)], lw)
+    assert [_engine(P, ds, m) for m in mix.models] == [0, 0, 1, 0]
+    assert _rel(mix.llks(ds), oracle.mix_llks(x, sig, cs, ms, lw)) < 1e-9
+    assert _rel(mix.infer_cluster(ds), oracle.mix_infer_cluster(x, sig, cs, ms, lw)) < 1e-8
