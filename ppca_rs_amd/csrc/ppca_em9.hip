@@ -579,6 +579,21 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         cnt = __builtin_amdgcn_readfirstlane(cnt < 0 ? 0 : (cnt > B ? B : cnt));
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Xwg + (int64_t)rel0 * p.ldx), 0, cnt * rowbytes, 0x00020000);
     };
+    // (round 6) The row list and the weights of a gathered / weighted pass used to be read where they are used -- one scalar load per
+    // row in front of its row request inside P4a's MFMA loop, one per row inside the staging -- and a scalar load's wait is
+    // lgkmcnt(0): it also drains the LDS operand reads / x~ stores in flight around it.  The gathered weighted pass of a mixture
+    // component ran at 1.5 us per 1 000 rows against 0.95 for the plain pass.  Now lane r < RPW of one VECTOR load holds the physical
+    // row (gidx) and the weight (gw) of the wave's row r of the tile requested / staged next, issued a whole trip before its use.
+    int gidx = 0;
+    double gw = 0.0;
+    auto fetch_meta = [&](int64_t tile) {
+        const int rel = (int)(tile - tile_begin) * B + wave * RPW + (lane_entry & (RPW - 1));
+        const int rc = rel < nrel ? rel : nrel - 1;  // (nrel >= 1 wherever this is called)
+        if constexpr (GATHER) {
+            if (rows_wg) gidx = rows_wg[rc];
+        }
+        if constexpr (WEIGHTED) gw = p.w[tile_begin * B + rc];
+    };
     auto load_row = [&](const __amdgpu_buffer_rsrc_t &trs, int64_t tile, int r) {
         typedef unsigned u4_t __attribute__((ext_vector_type(4)));
         if constexpr (GATHER) {
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 const int rel = (int)(tile - tile_begin) * B + wave * RPW + r;
                 const int rc = rel < nrel ? rel : nrel - 1;
                 const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<double *>(p.X + (int64_t)rows_wg[rc < 0 ? 0 : rc] * p.ldx), 0, rc < 0 ? 0 : rowbytes, 0x00020000);
+                    const_cast<double *>(p.X + (int64_t)__builtin_amdgcn_readlane(gidx, r) * p.ldx), 0, rc < 0 ? 0 : rowbytes, 0x00020000);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane_entry * 16, 1024 * h, E9_X_AUX);
@@ -666,7 +681,13 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         });
         // wave-uniform: a real row of one of THIS workgroup's tiles
         const bool mine = (int)(t - tile_begin) * B + ri < nmine;
-        const double wr = mine ? (WEIGHTED ? p.w[t * B + ri] : 1.0) : 0.0;  // (scalar load)
+        double wr = 1.0;
+        if constexpr (WEIGHTED) {  // (lane r of gw: fetch_meta)
+            const long long gb = __double_as_longlong(gw);
+            const int lo = __builtin_amdgcn_readlane((int)gb, r), hi = __builtin_amdgcn_readlane((int)(gb >> 32), r);
+            wr = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+        }
+        wr = mine ? wr : 0.0;
         xx_run += wr * pc_xx;
     };
     // staging lane map: lane l holds dims 128 h + 2 l + e (element q = 2 h + e) of a row.  The lane's four means and
@@ -701,6 +722,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 
     if (tile_begin < tile_end) {
         const __amdgpu_buffer_rsrc_t trs = tile_rsrc(tile_begin);
+        if constexpr (GATHER || WEIGHTED) fetch_meta(tile_begin);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) load_row(trs, tile_begin, r);
         if constexpr (CLDS) load_mu();
@@ -709,6 +731,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         load_pair(qbB, 4);
 #endif
         stage_tile(tile_begin, lane_entry);
+        if constexpr (GATHER || WEIGHTED) fetch_meta(tile_begin + 1);
     }
     role_barrier(fbar, fbar_target, lane_entry);
 
@@ -1178,6 +1201,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         // (its sample masks go into the slot of tile rel - 3: the back role's iterations up to rel - 2 must be over)
         if (rel >= 2) wait_counter(itdone, 4u * (unsigned)(rel - 1));
         stage_tile(tile + 1, lane);
+        if constexpr (GATHER || WEIGHTED) fetch_meta(tile + 2);  // (consumed one trip from here: P4a's row requests, the staging's weights)
         E9_FINE(13)
 #ifndef E9_EXP_NOB4  // (timing experiment, results wrong: what this barrier costs)
         role_barrier(fbar, fbar_target, lane_entry);

@@ -1454,6 +1454,8 @@ def test_multi_component_step_equals_component_by_component(oracle, tmp_path):
         np.testing.assert_array_equal(multi[case + "_c"], single[case + "_c"], err_msg=case)
         np.testing.assert_array_equal(multi[case + "_mean"], single[case + "_mean"], err_msg=case)
         np.testing.assert_array_equal(multi[case + "_sigma"], single[case + "_sigma"], err_msg=case)
+        for key in ("_llks", "_c", "_mean", "_sigma", "_lw", "_trace"):
+            assert np.isfinite(multi[case + key]).all(), (case, key)
         assert np.abs(multi[case + "_lw"] - single[case + "_lw"]).max() < 1e-12, case
         assert _rel(multi[case + "_trace"], single[case + "_trace"]) < 1e-13, case
     np.testing.assert_array_equal(multi["guard_llks"], single["guard_llks"])

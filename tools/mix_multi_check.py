@@ -30,8 +30,10 @@ def make(rng, d, k, nm, n, mask=0.3, weights=True):
     w = rng.uniform(0.5, 2.0, n) if weights else None
     if weights:
         w[5] = 0.0
-    start = P.PPCAMix([P.PPCAModel(1.0 + 0.1 * c, rng.standard_normal((d, k)), rng.standard_normal(d)) for c in range(nm)],
-                      np.log(rng.dirichlet(np.ones(nm) * 3)))
+    # (a start near the truth: from random models a component of so small a dataset can collapse onto one row, and every comparison
+    #  downstream would be NaN against NaN)
+    start = P.PPCAMix([P.PPCAModel(1.0 + 0.1 * c, truth[c][0] + 0.3 * rng.standard_normal((d, k)), truth[c][1] + 0.3 * rng.standard_normal(d))
+                       for c in range(nm)], np.log(rng.dirichlet(np.ones(nm) * 3)))
     return x, w, start
 
 
