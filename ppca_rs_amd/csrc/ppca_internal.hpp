@@ -172,6 +172,9 @@ hipError_t launch_em16(int k, int grid, const Em16Launch &a, hipStream_t s);
 // The log-likelihood sweep alone (ppca_llk.hip): per-sample llks (nullable) and the per-workgroup scalars; honours
 // a.qflag like the int8 instantiation of pass_kernel.
 hipError_t launch_llk2(int k, int grid, const PassArgs &a, hipStream_t s);
+// PPCAModel::smooth / extrapolate (recon modes 0 / 1) on the same eight-wave sweep (ppca_llk.hip, llk8_run<K, OUT>)
+bool recon8_covers(const PassArgs &a);
+hipError_t launch_recon8(int k, int grid, const PassArgs &a, hipStream_t s);
 // ... of ALL components of a mixture in one launch (same state size k <= FUSED_MAX_K, nm <= MIX_MAX): units = (component, run of
 // tiles), dealt so that the workgroups of one XCD walk the same rows for the different components (X from HBM once per iteration)
 bool mix_llk8_available();  // false under PPCA_LLK8=0

@@ -2215,6 +2215,7 @@ static hipError_t launch_pass_guarded(int grid, PassArgs a, hipStream_t s) {
     auto int8_pass = [&](const PassArgs &b) {
         if constexpr (!EM) {  // llk / llks alone: the two-tile sweep (ppca_llk.hip) unless PPCA_LLK2=0
             if (!b.states && !b.covs && !b.recon && llk2_enabled()) return launch_llk2(K, grid, b, s);
+            if (recon8_covers(b)) return launch_recon8(K, grid, b, s);  // smooth / extrapolate on the eight-wave sweep (round 6)
         }
         if constexpr (EM) {
             if (em8_enabled() && em9_enabled() && em9_covers(K)) return launch_em9(K, grid, b, s);  // ... with the solve pipelined across tiles (PPCA_EM8=0 switches both eight-wave kernels off)

@@ -370,7 +370,15 @@ __device__ __forceinline__ void store_row_sums4(const double (&pxx)[4], int lane
 
 // The sweep over the tiles [tile_begin, tile_end) of p's rows by ONE workgroup (the body of llk8_kernel; mix_llk8_kernel below walks
 // several (model, run of tiles) units with it).  scal: where the workgroup's scalars go (nullable).
-template <int K>
+// OUT (round 6): 0 the llk sweep; 1 / 2 the N x d output passes PPCAModel::smooth / extrapolate (ppca_model.rs:237-261 on :454-463:
+// C z + mean for every dimension / for the masked ones, the observed values passed through) on the same sweep -- the solver step also
+// runs the back substitution (z = M^-1 b into the sample's dead b-partial slots), then every wave forms eight of the round's 64 output
+// rows with the lane map of the staging (lane l: dims 128 h + 2 l, + 1: its two rows of C in registers, z broadcast from LDS, K
+// multiply-adds per element) and stores them as whole 16-byte pieces, 1 KB per instruction; extrapolate re-reads the rows (L2: they
+// were staged a round ago) and selects by the mask words still in LDS -- bit-exact pass-through.  The waves drop their table slices
+// for that phase and request them again behind it, as the solver wave always did.  Needs an even d (16-byte pieces).  The four-wave
+// pass_kernel<K, false> (5.3 / 5.7 ms at N = 4 M) formed the outputs on the fp64 MFMA, moved them through LDS and stored 8 bytes per lane.
+template <int K, int OUT = 0>
 __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const int64_t tile_begin, const int64_t tile_end, double *scal) {
     using cfg = CfgL8<K>;
     constexpr int KP = cfg::KP, NTP = cfg::NTP, B = cfg::B, XS = cfg::XS, CS = cfg::CS, GS = cfg::GS, BS = cfg::BS;
@@ -594,12 +602,81 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             double pm;
             int pe;
             post.factor([&](int e) { return g0[e]; }, s2, pm, pe);
-            const double quad = post.forward_quad([&](int a) { return ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; });
-            const double lk = sample_llk(xx, quad, lean_log(pm) + (double)pe * LN_2, s2, lnsig, m, K);
-            run_llk += wgt * lk;
-            run_w += wgt;
-            if (p.llks && mine) p.llks[row] = lk;
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (OUT == 0) {
+                const double quad = post.forward_quad([&](int a) { return ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; });
+                const double lk = sample_llk(xx, quad, lean_log(pm) + (double)pe * LN_2, s2, lnsig, m, K);
+                run_llk += wgt * lk;
+                run_w += wgt;
+                if (p.llks && mine) p.llks[row] = lk;
+                __builtin_amdgcn_sched_barrier(0);
+                load_table();
+            } else {
+                double z[K], quad, zz;
+                post.solve([&](int a) { return ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; }, z, quad, zz);
+                double *zr = B1 + lane * BS;  // (the first b partial of the sample is dead: its z goes there)
+#pragma unroll
+                for (int a = 0; a < K; ++a) zr[a] = z[a];
+                (void)xx; (void)m; (void)wgt; (void)pm; (void)pe;
+            }
+        }
+        if constexpr (OUT != 0) {
+            __syncthreads();
+            // (a fresh opaque copy of the lane index: everything the phase derives from it -- addresses, the re-read of the rows -- is computed
+            //  HERE, not hoisted above the barrier into the contraction, whose registers are full: hipcc did, and spilled the next tile's rows)
+            int lo = lane_entry;
+            asm volatile("" : "+v"(lo));
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+            static_for<2>([&](auto h_tag) {
+                constexpr int h = decltype(h_tag)::value;
+                __builtin_amdgcn_sched_barrier(0);  // (one half at a time: the second half's loads stay behind the first half's stores)
+                double c0[K], c1[K];
+                const double *cr = Cs + (128 * h + 2 * lo) * CS;
+#pragma unroll
+                for (int a = 0; a < K; ++a) {
+                    c0[a] = cr[a];
+                    c1[a] = cr[CS + a];
+                }
+                const d2_t mu2 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 * h + 2 * lo);
+                u4_t xin[RPW * 2];
+                if constexpr (OUT == 2) {  // every load of the phase before its first store (one in-order counter for both)
+#pragma unroll
+                    for (int r = 0; r < 2 * RPW; ++r) {
+                        const int si = 2 * RPW * wave + r;
+                        const int64_t row = (tile + (si >> 5)) * B + (si & (B - 1));
+                        const __amdgpu_buffer_rsrc_t xr1 = __builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<double *>(p.X + (row < n ? row : n - 1) * p.ldx), 0, rowbytes, 0x00020000);
+                        xin[r] = __builtin_amdgcn_raw_buffer_load_b128(xr1, lo * 16, 1024 * h, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 2 * RPW; ++r) {
+                    const int si = 2 * RPW * wave + r;  // sample of the round: slot si >> 5, row si & 31 of its tile
+                    const int64_t t = tile + (si >> 5);
+                    const int64_t row = t * B + (si & (B - 1));
+                    const bool ok = t < tile_end && row < n;  // (wave-uniform)
+                    const double *zr = B1 + si * BS;
+                    double o0 = mu2[0], o1 = mu2[1];
+#pragma unroll
+                    for (int a = 0; a < K; ++a) {
+                        const double za = zr[a];
+                        o0 = __builtin_fma(za, c0[a], o0);
+                        o1 = __builtin_fma(za, c1[a], o1);
+                    }
+                    if constexpr (OUT == 2) {
+                        const unsigned long long w0 = Ms[si * 4 + 2 * h], w1 = Ms[si * 4 + 2 * h + 1];
+                        const double x0 = __longlong_as_double(((long long)xin[r][1] << 32) | xin[r][0]);
+                        const double x1 = __longlong_as_double(((long long)xin[r][3] << 32) | xin[r][2]);
+                        o0 = ((w0 >> lo) & 1ull) ? x0 : o0;
+                        o1 = ((w1 >> lo) & 1ull) ? x1 : o1;
+                    }
+                    const long long b0 = __double_as_longlong(o0), b1v = __double_as_longlong(o1);
+                    const u4_t ov = u4_t{(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1v, (unsigned)(b1v >> 32)};
+                    const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(
+                        p.recon + (ok ? row : 0) * (int64_t)d, 0, ok ? rowbytes : 0, 0x00020000);  // (lanes past d, rows past n: dropped)
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, orow, lo * 16, 1024 * h, 0);
+                }
+            });
             load_table();
         }
         __syncthreads();
@@ -635,6 +712,23 @@ __global__ __launch_bounds__(512) void llk8_kernel(PassArgs p) {
     const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
     const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
     llk8_run<K>(p, sm, tile_begin, tile_end, p.scal_part + (int64_t)blockIdx.x * 8);
+}
+
+template <int K, int OUT>
+__global__ __launch_bounds__(512) void recon8_kernel(PassArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (p.qflag) {  // qprep's dynamic-range guard: pass_kernel<K, false, 4, false> runs instead
+        int unsafe = 0;
+#pragma unroll
+        for (int t = 0; t < CfgL8<K>::NTP; ++t) unsafe |= p.qflag[t];
+        if (unsafe) return;
+    }
+    constexpr int B = CfgL8<K>::B;
+    const int64_t ntiles = (p.n + B - 1) / B;
+    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t tile_end = tile_begin + tiles_per_wg < ntiles ? tile_begin + tiles_per_wg : ntiles;
+    llk8_run<K, OUT>(p, sm, tile_begin, tile_end, p.scal_part + (int64_t)blockIdx.x * 8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -738,6 +832,45 @@ static hipError_t launch_mix_llk8_t(int grid, const MixLlkArgs &a, hipStream_t s
     }
     hipLaunchKernelGGL((mix_llk8_kernel<K>), dim3(grid), dim3(512), lds, s, a);
     return hipGetLastError();
+}
+
+template <int K, int OUT>
+static hipError_t launch_recon8_t(int grid, const PassArgs &a, hipStream_t s) {
+    const size_t lds = sizeof(double) * CfgL8<K>::LDS_DOUBLES;
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&recon8_kernel<K, OUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((recon8_kernel<K, OUT>), dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+// smooth / extrapolate on the eight-wave sweep: recon modes 0 / 1 with an even d and nothing else asked of the pass (PPCA_RECON8=0:
+// the four-wave pass_kernel, A/B runs)
+bool recon8_covers(const PassArgs &a) {
+    static const bool on = [] {
+        const char *e = getenv("PPCA_RECON8");
+        return !(e && atoi(e) == 0);
+    }();
+    return on && llk8_enabled() && a.recon && !a.states && !a.covs && !a.llks && (a.recon_mode == 0 || a.recon_mode == 1) && (a.d & 1) == 0 &&
+           a.ldx == a.d;
+}
+hipError_t launch_recon8(int k, int grid, const PassArgs &a, hipStream_t s) {
+#define PPCA_R8(KK) case KK: return a.recon_mode == 0 ? launch_recon8_t<KK, 1>(grid, a, s) : launch_recon8_t<KK, 2>(grid, a, s);
+    switch (k) {
+#ifdef PPCA_DEV_K10
+        PPCA_R8(10)
+#else
+        PPCA_R8(1) PPCA_R8(2) PPCA_R8(3) PPCA_R8(4) PPCA_R8(5) PPCA_R8(6) PPCA_R8(7) PPCA_R8(8) PPCA_R8(9) PPCA_R8(10)
+#endif
+        default: return hipErrorInvalidValue;
+    }
+#undef PPCA_R8
 }
 
 // Runs of tiles per XCD group of workgroups for a launch of `grid` workgroups over nm components: the smallest count that deals

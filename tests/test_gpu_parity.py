@@ -1483,3 +1483,33 @@ def test_multi_component_sweep_with_a_guard_tripping_component(P, oracle):
     assert [_engine(P, ds, m) for m in mix.models] == [0, 0, 1, 0]
     assert _rel(mix.llks(ds), oracle.mix_llks(x, sig, cs, ms, lw)) < 1e-9
     assert _rel(mix.infer_cluster(ds), oracle.mix_infer_cluster(x, sig, cs, ms, lw)) < 1e-8
+
+
+@pytest.mark.parametrize("d,k", [(2, 1), (64, 4), (200, 10), (256, 10), (254, 7)])
+def test_output_rows_on_the_eight_wave_sweep(P, oracle, d, k):
+    """Round 6: PPCAModel.smooth / extrapolate (ppca_model.rs:237-261) for an even d <= 256, k <= 10 run on the eight-wave sweep
+    (recon8_kernel: back substitution in the solver step, the rows formed with the staging's lane map and stored as whole 16-byte
+    pieces).  Ragged n around the 64-sample round, an all-masked row, a fully observed row, the full grid and ONE workgroup walking
+    every round; extrapolate passes the observed values through bit-exactly."""
+    from ppca_rs_amd import _lib
+
+    rng = np.random.default_rng(1000 * d + k)
+    c, mu, s = rng.standard_normal((d, k)), rng.standard_normal(d), 0.3
+    m = P.PPCAModel(s, c, mu)
+    ctx = _lib.default_context()
+    try:
+        for n, limit in ((1, 0), (63, 0), (65, 1), (1000, 0), (1931, 1), (1931, 3)):
+            x = rng.standard_normal((n, k)) @ c.T + mu + s * rng.standard_normal((n, d))
+            x[rng.random((n, d)) < 0.3] = np.nan
+            x[0] = np.nan
+            if n > 2:
+                x[2] = rng.standard_normal(d)
+            ctx.set_grid_limit(limit)
+            ds = P.Dataset(x)
+            assert _rel(m.smooth(ds).numpy(), oracle.reconstruct(x, s, c, mu, "smooth")) < 1e-9, (n, limit)
+            ex = m.extrapolate(ds).numpy()
+            assert _rel(ex, oracle.reconstruct(x, s, c, mu, "extrapolate")) < 1e-9, (n, limit)
+            assert np.array_equal(ex[np.isfinite(x)], x[np.isfinite(x)]), (n, limit)
+            np.testing.assert_allclose(m.smooth(ds).numpy()[0], mu, rtol=0, atol=0)  # the all-masked row: z = 0, the mean exactly
+    finally:
+        ctx.set_grid_limit(0)
