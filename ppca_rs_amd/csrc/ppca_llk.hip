@@ -627,57 +627,92 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             asm volatile("" : "+v"(lo));
             typedef double d2_t __attribute__((ext_vector_type(2)));
             typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-            static_for<2>([&](auto h_tag) {
-                constexpr int h = decltype(h_tag)::value;
-                __builtin_amdgcn_sched_barrier(0);  // (one half at a time: the second half's loads stay behind the first half's stores)
-                double c0[K], c1[K];
-                const double *cr = Cs + (128 * h + 2 * lo) * CS;
+            constexpr int NR = 2 * RPW;  // rows of the round per wave
+            // Order of the phase: [extrapolate: the re-read of the wave's rows] -> the 2 x NR output pieces into registers -> the
+            // request of the wave's table slice -> the stores.  Loads and stores share one in-order counter: the slice requested
+            // BEHIND the stores would come back only after the stores are acknowledged (the next contraction waited for that).
+            u4_t ov[NR][2];
+            if constexpr (OUT == 2) {
 #pragma unroll
-                for (int a = 0; a < K; ++a) {
-                    c0[a] = cr[a];
-                    c1[a] = cr[CS + a];
+                for (int r = 0; r < NR; ++r) {
+                    const int si = NR * wave + r;
+                    const int64_t row = (tile + (si >> 5)) * B + (si & (B - 1));
+                    const __amdgpu_buffer_rsrc_t xr1 = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<double *>(p.X + (row < n ? row : n - 1) * p.ldx), 0, rowbytes, 0x00020000);
+                    ov[r][0] = __builtin_amdgcn_raw_buffer_load_b128(xr1, lo * 16, 0, 0);
+                    ov[r][1] = __builtin_amdgcn_raw_buffer_load_b128(xr1, lo * 16, 1024, 0);
                 }
-                const d2_t mu2 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 * h + 2 * lo);
-                u4_t xin[RPW * 2];
-                if constexpr (OUT == 2) {  // every load of the phase before its first store (one in-order counter for both)
+            }
+            // the halves h in [H0, H1) of the wave's NR rows: smooth takes both at once (z read once per row); extrapolate one after the
+            // other (its 2 x NR re-read pieces are in registers meanwhile: both halves' rows of C beside them do not fit)
+            auto form = [&](auto h0_tag, auto h1_tag) {
+                constexpr int H0 = decltype(h0_tag)::value, H1 = decltype(h1_tag)::value;
+                double c[2][2][K];
+                d2_t mu2[2];
 #pragma unroll
-                    for (int r = 0; r < 2 * RPW; ++r) {
-                        const int si = 2 * RPW * wave + r;
-                        const int64_t row = (tile + (si >> 5)) * B + (si & (B - 1));
-                        const __amdgpu_buffer_rsrc_t xr1 = __builtin_amdgcn_make_buffer_rsrc(
-                            const_cast<double *>(p.X + (row < n ? row : n - 1) * p.ldx), 0, rowbytes, 0x00020000);
-                        xin[r] = __builtin_amdgcn_raw_buffer_load_b128(xr1, lo * 16, 1024 * h, 0);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 2 * RPW; ++r) {
-                    const int si = 2 * RPW * wave + r;  // sample of the round: slot si >> 5, row si & 31 of its tile
-                    const int64_t t = tile + (si >> 5);
-                    const int64_t row = t * B + (si & (B - 1));
-                    const bool ok = t < tile_end && row < n;  // (wave-uniform)
-                    const double *zr = B1 + si * BS;
-                    double o0 = mu2[0], o1 = mu2[1];
+                for (int h = H0; h < H1; ++h) {
+                    const double *cr = Cs + (128 * h + 2 * lo) * CS;
 #pragma unroll
                     for (int a = 0; a < K; ++a) {
-                        const double za = zr[a];
-                        o0 = __builtin_fma(za, c0[a], o0);
-                        o1 = __builtin_fma(za, c1[a], o1);
+                        c[h][0][a] = cr[a];
+                        c[h][1][a] = cr[CS + a];
                     }
-                    if constexpr (OUT == 2) {
-                        const unsigned long long w0 = Ms[si * 4 + 2 * h], w1 = Ms[si * 4 + 2 * h + 1];
-                        const double x0 = __longlong_as_double(((long long)xin[r][1] << 32) | xin[r][0]);
-                        const double x1 = __longlong_as_double(((long long)xin[r][3] << 32) | xin[r][2]);
-                        o0 = ((w0 >> lo) & 1ull) ? x0 : o0;
-                        o1 = ((w1 >> lo) & 1ull) ? x1 : o1;
-                    }
-                    const long long b0 = __double_as_longlong(o0), b1v = __double_as_longlong(o1);
-                    const u4_t ov = u4_t{(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1v, (unsigned)(b1v >> 32)};
-                    const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(
-                        p.recon + (ok ? row : 0) * (int64_t)d, 0, ok ? rowbytes : 0, 0x00020000);  // (lanes past d, rows past n: dropped)
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, orow, lo * 16, 1024 * h, 0);
+                    mu2[h] = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 * h + 2 * lo);
                 }
-            });
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int si = NR * wave + r;  // sample of the round: slot si >> 5, row si & 31 of its tile
+                    const double *zr = B1 + si * BS;
+                    double o[2][2];
+#pragma unroll
+                    for (int h = H0; h < H1; ++h) {
+                        o[h][0] = mu2[h][0];
+                        o[h][1] = mu2[h][1];
+                    }
+#pragma unroll
+                    for (int a = 0; a < K; ++a) {
+                        const double za = zr[a];  // (one address for the wave: a broadcast read)
+#pragma unroll
+                        for (int h = H0; h < H1; ++h) {
+                            o[h][0] = __builtin_fma(za, c[h][0][a], o[h][0]);
+                            o[h][1] = __builtin_fma(za, c[h][1][a], o[h][1]);
+                        }
+                    }
+#pragma unroll
+                    for (int h = H0; h < H1; ++h) {
+                        if constexpr (OUT == 2) {
+                            const unsigned long long w0 = Ms[si * 4 + 2 * h], w1 = Ms[si * 4 + 2 * h + 1];
+                            const double x0 = __longlong_as_double(((long long)ov[r][h][1] << 32) | ov[r][h][0]);
+                            const double x1 = __longlong_as_double(((long long)ov[r][h][3] << 32) | ov[r][h][2]);
+                            o[h][0] = ((w0 >> lo) & 1ull) ? x0 : o[h][0];
+                            o[h][1] = ((w1 >> lo) & 1ull) ? x1 : o[h][1];
+                        }
+                        const long long b0 = __double_as_longlong(o[h][0]), b1v = __double_as_longlong(o[h][1]);
+                        ov[r][h] = u4_t{(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1v, (unsigned)(b1v >> 32)};
+                    }
+                }
+            };
+            if constexpr (OUT == 1) {
+                form(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            } else {
+                form(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                form(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
             load_table();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int si = NR * wave + r;
+                const int64_t t = tile + (si >> 5);
+                const int64_t row = t * B + (si & (B - 1));
+                const bool ok = t < tile_end && row < n;  // (wave-uniform)
+                const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(
+                    p.recon + (ok ? row : 0) * (int64_t)d, 0, ok ? rowbytes : 0, 0x00020000);  // (lanes past d, rows past n: dropped)
+                __builtin_amdgcn_raw_buffer_store_b128(ov[r][0], orow, lo * 16, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ov[r][1], orow, lo * 16, 1024, 0);
+            }
         }
         __syncthreads();
     }
