@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # gfx950 correction calibrated on a known byte count): profiles/r01/README.md
 PMC_BYTES_PER_SAMPLE = 2077.5
 FP64_PEAK_TFLOPS = 78.6  # fp64 vector = fp64 matrix spec (dense MFMA peak for f64)
-TRAFFIC_FILES = ("profiles/r05/traffic.json", "profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
+TRAFFIC_FILES = ("profiles/r06/traffic.json", "profiles/r05/traffic.json", "profiles/r04/traffic.json", "profiles/r03/traffic.json", "profiles/r02/traffic.json")
 
 
 def algorithmic_bytes_per_sample(d: int) -> float:
@@ -158,8 +158,11 @@ def self_launch(args) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         err = open(os.path.join(tmp, f"rank{r}.err"), "w")
-        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        # (rank 0's stdout goes to a FILE, not a pipe: nobody reads while the ranks run, and a pipe would block a chatty rank at 64 KB)
+        out = open(os.path.join(tmp, "rank0.out"), "w") if r == 0 else subprocess.DEVNULL
         procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err), err))
+        if r == 0:
+            out.close()
     def stop_children(signum=None, frame=None):  # never leave ranks behind when the launcher itself is stopped
         for p, _ in procs:
             if p.poll() is None:
@@ -182,8 +185,6 @@ def self_launch(args) -> int:
     while pending and failed is None:
         for r in sorted(pending):
             p, _ = procs[r]
-            if r == 0 and p.stdout is not None:
-                pass  # (read at the end: one JSON line fits the pipe buffer)
             rc = p.poll()
             if rc is not None:
                 pending.discard(r)
@@ -199,8 +200,8 @@ def self_launch(args) -> int:
                 procs[r][0].wait(timeout=20)
             except subprocess.TimeoutExpired:
                 procs[r][0].kill()
-    if procs[0][0].stdout is not None:
-        out0 = procs[0][0].stdout.read()
+    with open(os.path.join(tmp, "rank0.out"), "rb") as fh:
+        out0 = fh.read()
     for _, err in procs:
         err.close()
     if failed is not None:
@@ -234,7 +235,7 @@ def traffic_from_profiles(rows_local: int):
 def sustained_mfma_from_profiles():
     """What a loop of nothing but independent MFMAs sustains on this part (tools/mfma_peak, run on the GPU box before the
     bench line; reported beside the guide's nominal peak, never instead of it)."""
-    for rel in ("profiles/r05/mfma_peak.json", "profiles/r04/mfma_peak.json"):
+    for rel in ("profiles/r06/mfma_peak.json", "profiles/r05/mfma_peak.json", "profiles/r04/mfma_peak.json"):
         try:
             with open(os.path.join(ROOT, rel)) as fh:
                 pj = json.load(fh)
@@ -572,23 +573,28 @@ def main() -> None:
             tflops, gbs = flops_step / t_step / 1e12, bytes_step / t_step / 1e9
             fp64_bound = False  # the mixture is reported against the ONE-pass byte figure (X read once per iteration)
             llk_kernel = "llk2_kernel" if os.environ.get("PPCA_LLK8") == "0" else "llk8_kernel"
+            one_launch = os.environ.get("PPCA_MIX_MULTI") != "0" and llk_kernel == "llk8_kernel" and nm <= 16
             em_kernel = ("pass_kernel" if os.environ.get("PPCA_EM8") == "0" else
                          "em8_kernel" if os.environ.get("PPCA_EM9") == "0" else "em9_kernel")
-            kernel_name = (f"one mixture EM iteration = {nm} {llk_kernel}<{k}> sweeps + {nm} gathered {em_kernel}<{k}, true> passes + "
-                           "finalisations (timed as one region" + (": ONE C-ABI call)" if em._one_call else ", composed from the C-ABI building blocks)"))
+            kernel_name = ((f"one mixture EM iteration = ONE mix_llk8_kernel<{k}> launch for the {nm} llk sweeps (X read once)" if one_launch
+                            else f"one mixture EM iteration = {nm} {llk_kernel}<{k}> sweeps") +
+                           f" + {nm} gathered {em_kernel}<{k}, true> passes + finalisations (timed as one region" + (": ONE C-ABI call)" if em._one_call else ", composed from the C-ABI building blocks)"))
             kern_avg_ms, launches_rep = 1e3 * t_step, args.steps
             traffic, traffic_src = None, None
             if (d, k, nm) == (256, 10, 8):
                 # HBM bytes per sample of ONE steady-state mixture iteration over every kernel it launches (tools/pmc_mix.py under
                 # separate rocprofv3 FETCH_SIZE / WRITE_SIZE passes, tools/make_traffic_all.py), committed with its commit
-                try:
-                    with open(os.path.join(ROOT, "profiles/r05/traffic_cfg5.json")) as fh:
-                        tj = json.load(fh)
-                    traffic = tj["hbm_bytes_per_sample"] * rows_local
-                    traffic_src = (f"profiles/r05/traffic_cfg5.json (commit {tj.get('commit')}, {tj.get('n_samples')} rows x {tj.get('steps')} steady-state "
-                                   "mixture iterations, all kernels; fabric bytes, Infinity-Cache hits included)")
-                except (OSError, KeyError, ValueError):
-                    pass
+                multi = os.environ.get("PPCA_MIX_MULTI") != "0"
+                for rel in (("profiles/r06/traffic_cfg5.json",) if multi else ()) + ("profiles/r05/traffic_cfg5.json",):
+                    try:
+                        with open(os.path.join(ROOT, rel)) as fh:
+                            tj = json.load(fh)
+                        traffic = tj["hbm_bytes_per_sample"] * rows_local
+                        traffic_src = (f"{rel} (commit {tj.get('commit')}, {tj.get('n_samples')} rows x {tj.get('steps')} steady-state "
+                                       "mixture iterations, all kernels; fabric bytes, Infinity-Cache hits included)")
+                        break
+                    except (OSError, KeyError, ValueError):
+                        continue
         else:
             kern_avg_ms = kern_ms / max(launches, 1)
             launches_rep = launches
@@ -605,7 +611,7 @@ def main() -> None:
             if (d, k) == (1024, 64):
                 # config 4: HBM bytes per sample and EM step over EVERY kernel of the split pipeline (2 x FETCH_SIZE + WRITE_SIZE
                 # by separate rocprofv3 PMC passes of tools/pmc_generic.py), committed with the commit it was measured on
-                for rel in ("profiles/r05/traffic_cfg4.json", "profiles/r04/traffic_cfg4.json"):
+                for rel in ("profiles/r06/traffic_cfg4.json", "profiles/r05/traffic_cfg4.json", "profiles/r04/traffic_cfg4.json"):
                     try:
                         with open(os.path.join(ROOT, rel)) as fh:
                             tj = json.load(fh)

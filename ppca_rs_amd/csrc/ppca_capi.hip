@@ -656,7 +656,10 @@ extern "C" int ppca_dataset_scale_rows(ppca_dataset *ds, const int64_t *rows, in
     if (!ds || (n_rows > 0 && !rows) || n_rows < 0) return fail(PPCA_ERR_INVALID, "bad arguments");
     for (int64_t i = 0; i < n_rows; ++i)
         if (rows[i] < 0 || rows[i] >= ds->n) return fail(PPCA_ERR_INVALID, "row %lld is outside the dataset", (long long)rows[i]);
-    if (!ds->xbuf || ds->X != static_cast<const double *>(ds->xbuf->p)) return fail(PPCA_ERR_INVALID, "the dataset does not own its rows (a slice or a weighted view)");
+    // (a dataset made by ppca_dataset_from_device borrows the caller's `const double *` rows: xbuf->p == X there too, so the
+    //  pointer test alone let this hook write through memory the caller had handed over read-only -- advisor, round 5)
+    if (!ds->xbuf || !ds->xbuf->owned || ds->X != static_cast<const double *>(ds->xbuf->p))
+        return fail(PPCA_ERR_INVALID, "the dataset does not own its rows (a slice, a weighted view or borrowed device memory)");
     ppca_ctx *ctx = ds->ctx;
     USE_CTX(ctx);
     if (n_rows == 0) return PPCA_OK;
@@ -768,9 +771,17 @@ static int qtab_bind(ppca_ctx *ctx, const ppca_model *model, PassArgs &a) {
         return !(e && atoi(e) == 0);
     }();
     a.skip_qprep = cache && ctx->qtab_model == model->buf->p && ctx->qtab_stamp == model->stamp;
-    ctx->qtab_model = model->buf->p;
-    ctx->qtab_stamp = model->stamp;
+    // The table becomes this model's only when the pass that builds it has been ENQUEUED (qtab_commit): an early return between the
+    // two -- a failed allocation, a pinned engine that launches no qprep -- must not leave the mark on a table nobody built
+    // (advisor, round 5).  Until then the context owns no table.
+    if (!a.skip_qprep) ctx->qtab_model = nullptr;
     return PPCA_OK;
+}
+static void qtab_commit(ppca_ctx *ctx, const ppca_model *model, bool built) {
+    if (built) {
+        ctx->qtab_model = model->buf->p;
+        ctx->qtab_stamp = model->stamp;
+    }
 }
 
 // rows / wsel / nsel: gathered pass over nsel rows of the dataset (fused path only): sample i is row rows[i] with
@@ -844,6 +855,7 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
         HIP_TRY(hipEventRecord(e0, ctx->stream));
     }
     HIP_TRY(launch_pass_em(model->k, grid, a, ctx->stream));
+    qtab_commit(ctx, model, fused_gram_mode() != 1);  // (the fp64-pinned engine launches no qprep_kernel)
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(e1, ctx->stream));
         ctx->events.emplace_back(e0, e1);
@@ -1167,6 +1179,7 @@ static int run_post(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model, do
         a.dbg = static_cast<double *>(dbg->p);
 #endif
         HIP_TRY(launch_pass_post(model->k, grid, a, ctx->stream));
+        qtab_commit(ctx, model, fused_gram_mode() != 1);
         HIP_TRY(launch_reduce_partials(scal, grid, 8, scal + (size_t)grid * 8, ctx->stream));
 #ifdef PPCA_PHASE_TIMING
         if (!states_dev && !covs_dev && !recon_dev) {
@@ -1972,6 +1985,7 @@ extern "C" int ppca_gram_engine(ppca_ctx *ctx, const ppca_model *model, int32_t 
     if (int rc = qtab_bind(ctx, model, a)) return rc;  // (launch_gram_guard always builds the table: it is this model's afterwards)
     int forced = -1;
     HIP_TRY(launch_gram_guard(model->k, a, ctx->stream, &forced));
+    qtab_commit(ctx, model, forced < 0);  // (a pinned engine builds no table)
     if (forced >= 0) {
         *engine = forced;
         return PPCA_OK;

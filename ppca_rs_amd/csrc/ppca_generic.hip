@@ -1882,13 +1882,16 @@ static hipError_t launch_solve_bc(const SolveArgs &a, int grid, hipStream_t s) {
 // sample of the lane-per-row forms above.  The 16 x 16 diagonal blocks are factored and inverted by the lanes
 // themselves (lane = row, four redundant copies, uniform LDS reads for the shared operands).  Outputs leave through
 // the packed index (coalesced), z = M^-1 b by symmetric row reads.
-constexpr int SOLVE_LDB = 18;
-constexpr int solve_mfma_waves(int nb) { return nb == 4 ? 3 : 4; }
+// (round 6) NB = 5 .. 8: state sizes 65 .. 128 (the reference bounds k nowhere, ppca_model.rs:51-70).  Round 5 gave them one
+// WORKGROUP per matrix with a __syncthreads() per column (solve_big_kernel: 1.2 s per million systems at k = 65); the blocked form
+// needs nothing but LDS -- 36 KB (NB = 5) to 76 KB (NB = 8: blocks unpadded) per sample, so 4 / 3 / 2 / 2 waves per CU.
+constexpr int solve_ld(int nb) { return nb == 8 ? 16 : 18; }
+constexpr int solve_mfma_waves(int nb) { return nb <= 3 ? 4 : nb == 4 ? 3 : nb == 5 ? 4 : nb == 6 ? 3 : 2; }
 template <int NB>
 __device__ __forceinline__ void solve_mfma_body(const SolveArgs &a) {
     // the lower block triangle only, block after block (row stride LD inside a 16 x 16 block): 24 KB per sample at NB = 4
     // instead of 34, so that two workgroups (of three waves there) share a CU -- two waves per SIMD
-    constexpr int N = 16 * NB, LD = SOLVE_LDB, BSZ = 16 * LD, NBK = NB * (NB + 1) / 2, W = solve_mfma_waves(NB);
+    constexpr int N = 16 * NB, LD = solve_ld(NB), BSZ = 16 * LD, NBK = NB * (NB + 1) / 2, W = solve_mfma_waves(NB);
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1940,12 +1943,7 @@ __device__ __forceinline__ void solve_mfma_body(const SolveArgs &a) {
         // ---- M into LDS, full symmetric, identity padding; b.  The packed Gram is requested in one burst (NPK loads
         // in flight per lane) before the first LDS store; each lane walks the packed index by 64 (no square roots).
         constexpr int NPK = (N * (N + 1) / 2 + 63) / 64;
-        double gv[NPK];
-#pragma unroll
-        for (int q = 0; q < NPK; ++q) {
-            const int e = lane + 64 * q;
-            gv[q] = g[e < kp ? e : kp - 1];
-        }
+        constexpr int NPC = NPK <= 33 ? NPK : 32;  // loads in flight per lane (NB > 4: bursts of 32 -- 129 at once would be 258 registers)
         if (k < N) {
             for (int e = lane; e < NBK * BSZ; e += 64) Am[e] = 0.0;
             for (int e = lane; e < N; e += 64)
@@ -1957,17 +1955,25 @@ __device__ __forceinline__ void solve_mfma_body(const SolveArgs &a) {
             while ((r + 1) * (r + 2) / 2 <= lane) ++r;
             while (r * (r + 1) / 2 > lane) --r;
             int c = lane - r * (r + 1) / 2;
+            for (int q0 = 0; q0 < NPK; q0 += NPC) {
+                double gv[NPC];
 #pragma unroll
-            for (int q = 0; q < NPK; ++q) {
-                if (lane + 64 * q < kp) {
-                    const double v = gv[q] + (r == c ? s2 : 0.0);
-                    *at(r, c) = v;
-                    if ((r >> 4) == (c >> 4)) *at(c, r) = v;  // (diagonal blocks are kept whole: their factorisation reads rows)
+                for (int q = 0; q < NPC; ++q) {
+                    const int e = lane + 64 * (q0 + q);
+                    gv[q] = g[e < kp ? e : kp - 1];
                 }
-                c += 64;
-                while (c > r) {
-                    c -= r + 1;
-                    ++r;
+#pragma unroll
+                for (int q = 0; q < NPC; ++q) {
+                    if (lane + 64 * (q0 + q) < kp) {
+                        const double v = gv[q] + (r == c ? s2 : 0.0);
+                        *at(r, c) = v;
+                        if ((r >> 4) == (c >> 4)) *at(c, r) = v;  // (diagonal blocks are kept whole: their factorisation reads rows)
+                    }
+                    c += 64;
+                    while (c > r) {
+                        c -= r + 1;
+                        ++r;
+                    }
                 }
             }
         }
@@ -2047,7 +2053,7 @@ __device__ __forceinline__ void solve_mfma_body(const SolveArgs &a) {
                 stC(blk(ii, l), acc);
             }
         // ---- z = M^-1 b (lane = row; the strict upper part is read through the symmetric entry), traces
-        double zv[N / 64 > 0 ? N / 64 : 1];
+        double zv[(N + 63) / 64];
         double quad = 0.0, zz = 0.0, tr = 0.0;
 #pragma unroll
         for (int q = 0; q < (N + 63) / 64; ++q) {
@@ -2093,6 +2099,9 @@ __device__ __forceinline__ void solve_mfma_body(const SolveArgs &a) {
                 }
             }
             if (lane < k) bz[lane] = wgt * zv[0];
+            if constexpr (N > 64) {
+                if (lane + 64 < k) bz[lane + 64] = wgt * zv[1];
+            }
             if (lane == 0) {
                 bz[k] = wgt;
                 double *sc = a.sc + i * 4;
@@ -2119,6 +2128,12 @@ __device__ __forceinline__ void solve_mfma_body(const SolveArgs &a) {
                 bz[lane] = zv[0];
                 if (a.states) a.states[i * k + lane] = zv[0];
             }
+            if constexpr (N > 64) {
+                if (lane + 64 < k) {
+                    bz[lane + 64] = zv[1];
+                    if (a.states) a.states[i * k + lane + 64] = zv[1];
+                }
+            }
             if (lane == 0) {
                 double *sc = a.sc + i * 4;
                 sc[0] = 0.0;
@@ -2127,6 +2142,9 @@ __device__ __forceinline__ void solve_mfma_body(const SolveArgs &a) {
                 sc[3] = 0.0;
                 if (a.llks) a.llks[i] = lk;
             }
+        }
+        if constexpr (N > 64) {  // (bz of the sample is read in the image phase and written here through lanes of ONE wave: ordered)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
 }
@@ -2144,9 +2162,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int NB>
 static hipError_t launch_solve_mfma(const SolveArgs &a, int n_cu, hipStream_t s) {
     constexpr int N = 16 * NB, W = solve_mfma_waves(NB);
-    const size_t lds = sizeof(double) * W * (NB * (NB + 1) / 2 * 16 * SOLVE_LDB + 2 * N);
+    const size_t lds = sizeof(double) * W * (NB * (NB + 1) / 2 * 16 * solve_ld(NB) + 2 * N);
     // PPCA_SOLVE_OCC2=0: one workgroup per CU with the whole register file (A/B runs; the form of rounds 2-3)
-    static const bool occ2 = [] {
+    static const bool occ2 = NB <= 4 && [] {
         const char *e = getenv("PPCA_SOLVE_OCC2");
         return !(e && atoi(e) == 0);
     }();
@@ -2159,18 +2177,35 @@ static hipError_t launch_solve_mfma(const SolveArgs &a, int n_cu, hipStream_t s)
     if (lds > 65536 && !(done.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_mfma_kernel<NB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_mfma_occ2_kernel<NB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if constexpr (NB <= 4) {
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_mfma_occ2_kernel<NB>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         if (e != hipSuccess) return e;
         done.fetch_or(bit, std::memory_order_release);
     }
-    if (occ2) hipLaunchKernelGGL((solve_mfma_occ2_kernel<NB>), dim3(grid), dim3(64 * W), lds, s, a);
-    else hipLaunchKernelGGL((solve_mfma_kernel<NB>), dim3(grid), dim3(64 * W), lds, s, a);
+    if constexpr (NB <= 4) {
+        if (occ2) {
+            hipLaunchKernelGGL((solve_mfma_occ2_kernel<NB>), dim3(grid), dim3(64 * W), lds, s, a);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((solve_mfma_kernel<NB>), dim3(grid), dim3(64 * W), lds, s, a);
     return hipGetLastError();
 }
 static hipError_t launch_solve(const SolveArgs &a, int n_cu, hipStream_t s) {
-    if (a.k > 64) return launch_solve_big(a, n_cu, s);
+    if (a.k > 64) {
+        static const bool big = [] {  // PPCA_SOLVE_BIG=1: the workgroup-per-matrix solver of round 5 (A/B runs)
+            const char *e = getenv("PPCA_SOLVE_BIG");
+            return e && atoi(e) == 1;
+        }();
+        if (big) return launch_solve_big(a, n_cu, s);
+        if (a.k <= 80) return launch_solve_mfma<5>(a, n_cu, s);
+        if (a.k <= 96) return launch_solve_mfma<6>(a, n_cu, s);
+        if (a.k <= 112) return launch_solve_mfma<7>(a, n_cu, s);
+        return launch_solve_mfma<8>(a, n_cu, s);
+    }
     int grid = (int)std::min<int64_t>((a.n + 3) / 4, (int64_t)n_cu);
     if (grid < 1) grid = 1;
     static const bool reg = [] {  // PPCA_GENERIC_REG_SOLVE=1: the v_readlane-broadcast form (A/B runs)
@@ -2761,7 +2796,13 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
     GenWs W = carve(ws, d, k, n);
     const double *mean = model + MODEL_HDR + (int64_t)d * k;
     const double *Cm = model + MODEL_HDR;
-    const bool i8 = generic_i8() && k <= 64;  // (k > 64: the fp64 contractions and the workgroup-per-matrix solver, no performance claim)
+    // (round 6) k = 65 .. 128 run the int8-sliced contractions too (their tables, guards and the int8 GEMM are not bound in k; only the
+    // fused pre-solve pass is: those sizes take the three separate passes) -- PPCA_GENERIC_BIG_FP64=1: the fp64 contractions of round 5
+    static const bool big_fp64 = [] {
+        const char *e = getenv("PPCA_GENERIC_BIG_FP64");
+        return e && atoi(e) == 1;
+    }();
+    const bool i8 = generic_i8() && (k <= 64 || !big_fp64);
     if (em && i8 && em16_enabled() && em16_covers(d, k)) return run_em16(X, ldx, w, n, d, k, model, stats, W, n_cu, s);
     {
         const int64_t tot = (int64_t)d * kp;
@@ -2954,7 +2995,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
 // otherwise -1 and *flag_dev points at the guard flag (0 = int8-sliced, non-zero = fp64) the digit kernels just wrote.
 // ws: a workspace of generic_workspace_bytes(d, k, 1).
 hipError_t generic_gram_guard(int d, int k, const double *model, void *ws, hipStream_t s, const int **flag_dev, int *forced) {
-    if (!generic_i8() || k > 64) {
+    if (!generic_i8() || (k > 64 && getenv("PPCA_GENERIC_BIG_FP64") && atoi(getenv("PPCA_GENERIC_BIG_FP64")) == 1)) {
         *forced = 1;
         return hipSuccess;
     }
