@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPCA_ABI_VERSION 5
+#define PPCA_ABI_VERSION 6
 
 typedef enum ppca_status {
     PPCA_OK = 0,
@@ -307,6 +307,13 @@ int ppca_mix_reconstruct(ppca_ctx *ctx, ppca_dataset *ds, ppca_model *const *mod
  * pipelines, the periodic flush of the integer accumulators) under the oracle.  n_workgroups <= 0 restores the device's
  * CU count.  Results do not depend on the grid beyond the order of the partial sums. */
 int ppca_ctx_set_grid_limit(ppca_ctx *ctx, int32_t n_workgroups);
+/* (ABI 6) Test / measurement hook of the EM pass's int8 form of the mask-side statistics (k <= 10): a 32-sample tile with at most
+ * max_rows rows that do not fit the fixed-point form -- outlier samples, heavy sample weights -- sends those rows round it (exact
+ * fp64 additions into the accumulators, what the reference's f64 sums do with such a row, ppca_model.rs:297-306) instead of raising
+ * the exponents of its workgroup for every later row.  Default 8; 0 = the behaviour of ABI <= 5 (every such tile raises the
+ * exponents; the device-side guard then repeats the affected workgroups' slices on the fp64 engine: ppca_em_last_fallback), which
+ * the tests of that guard select.  Values above 32 mean 32. */
+int ppca_ctx_set_heavy_rows(ppca_ctx *ctx, int32_t max_rows);
 /* Diagnostic counters of the int8 statistics contraction of the EM pass on this context's device since the last reset:
  * out8[0..3] the eight-wave kernel (k <= 10), out8[4..7] the two-kernel pass (k = 11..16): [0] tiles cut again after the
  * fixed-point exponents were raised (beyond each workgroup's first tile), [1] periodic flushes of the int64

@@ -120,6 +120,7 @@ SIGNATURES = {
     "ppca_mix_em_step_sharded": (C.c_int, [C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int32, C.POINTER(Prior), c_void_pp, C.c_void_p, c_double_p]),
     "ppca_em_step_group": (C.c_int, [c_void_pp, C.c_int32, c_void_pp, c_void_pp, C.POINTER(Prior), c_void_pp, c_double_p]),
     "ppca_ctx_set_grid_limit": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ppca_ctx_set_heavy_rows": (C.c_int, [C.c_void_p, C.c_int32]),
     "ppca_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "ppca_em_last_guard": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "ppca_dataset_scale_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_double]),
@@ -217,6 +218,11 @@ class Context:
     def set_grid_limit(self, n_workgroups: int = 0) -> None:
         """Test hook (ppca_ctx_set_grid_limit): cap the workgroups of every persistent-grid launch; 0 restores."""
         check(lib().ppca_ctx_set_grid_limit(self.handle, int(n_workgroups)))
+
+    def set_heavy_rows(self, max_rows: int = 8) -> None:
+        """Test hook (ppca_ctx_set_heavy_rows): rows of a tile that may go round the fixed-point form of the EM pass's mask-side
+        statistics (default 8; 0: every tile with such a row raises its workgroup's exponents, as before ABI 6)."""
+        check(lib().ppca_ctx_set_heavy_rows(self.handle, int(max_rows)))
 
     def debug_counters(self, reset: bool = True):
         """ppca_debug_counters: 8 counters of the EM pass's int8 statistics contraction (see include/ppca_hip.h)."""

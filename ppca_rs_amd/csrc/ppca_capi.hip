@@ -828,6 +828,7 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
     a.model = model->p();
     a.part = static_cast<double *>(ctx->part->p);
     a.no_llk = ctx->skip_llk;
+    a.heavy_max = ctx->heavy_max;
     if (int rc = qtab_bind(ctx, model, a)) return rc;
     // the workgroups' rounding bounds, their column sums, then two int arrays: flagged workgroups as flags and as a list
     if (int rc = ensure(ctx->errb, ctx->errb_cap, sizeof(double) * ((size_t)grid + 1) * W_GUARD_NCOL + sizeof(int) * 2 * (size_t)grid)) return rc;
@@ -1606,6 +1607,7 @@ static int mix_em_step_multi(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, p
         a.model = models_in[c]->p();
         a.part = part + (size_t)c * grid * len;
         a.no_llk = 1;  // (the component passes' own llk is never read)
+        a.heavy_max = ctx->heavy_max;
         fused_qtab_layout(tab[c], a);
         a.skip_qprep = 1;
         a.errb = static_cast<double *>(ctx->errb->p) + errb_doubles * c;
@@ -1894,6 +1896,13 @@ extern "C" int ppca_ctx_set_grid_limit(ppca_ctx *ctx, int32_t n_workgroups) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "null context");
     USE_CTX(ctx);
     ctx->n_cu = (n_workgroups > 0 && n_workgroups < ctx->n_cu_device) ? n_workgroups : ctx->n_cu_device;
+    return PPCA_OK;
+}
+
+extern "C" int ppca_ctx_set_heavy_rows(ppca_ctx *ctx, int32_t max_rows) {
+    if (!ctx) return fail(PPCA_ERR_INVALID, "null context");
+    USE_CTX(ctx);
+    ctx->heavy_max = max_rows < 0 ? 0 : (max_rows > 32 ? 32 : max_rows);
     return PPCA_OK;
 }
 

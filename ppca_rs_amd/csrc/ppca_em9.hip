@@ -85,6 +85,9 @@ constexpr int E9_FLUSH_GROUPS = 100;
                        // wait (first half of the Gram 2.40 -> 2.12 k cycles per tile, b loop 2.70 -> 2.87 k: 100.7 against 100.8 it/s); on layout
                        // B, whose b loop waits for 16 instead of 48 loads, + 0.3 % (with nt row loads 104.2-104.4 against 103.2-103.4)
 #endif
+#ifndef E9_HEAVY_BUDGET
+#define E9_HEAVY_BUDGET 8  // tiles per flush window (200 tiles) whose rows above the scale go round the fixed-point form (heavy_add)
+#endif
 #ifndef E9_PLANES_PACKED
 #define E9_PLANES_PACKED 1
 #endif
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
     for (int idx = tid; idx < 2 * B * GS; idx += 512) Gs[idx] = 1.0;  // (something finite for the back role to cut)
 #endif
     if (tid < 8) ctr[tid] = 0u;
+    if (tid < 4) Ex[NCOL + tid] = 0;  // (heavy-row words of the back role's cold path)
     if (tid < NCOL) sm[cfg::OFF_EB + tid] = 0.0;
     if (tid == 0) {
         sm[cfg::OFF_K] = s2_k;
@@ -287,6 +291,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         int pending = 0;         // 1: the previous tile's planes wait in P0 for their partner
         int have_scale = 0, flushed = 0, groups = 0;
         int n_rescale = 0, n_flush = 0;  // (wave-uniform: diagnostic counters)
+        int hbudget = E9_HEAVY_BUDGET;   // tiles of the current flush window that may still send rows round the fixed-point form
         // Rounding bound of the cut, per column this lane covers (c = 16 t + l15), for wguard_kernel (ppca_kernels.hip): every
         // flush window adds 4 sqrt(rows of the window) quanta 2^(E_c - F) of the exponents it was cut under.
         double *ebs = sm + cfg::OFF_EB;  // (in LDS: touched at flushes only, by the role's first wave)
@@ -302,11 +307,15 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 
         // ---- digit planes of the current tile's rows under the exponents Ex; returns (wave-uniform) whether an entry
         // of a live column did not fit.  Item = (column c, 16-sample chunk): NCOL / 2 items per wave.
-        auto digitise = [&](int lane, int dst_bytes) -> bool {
+        // heavy_tag = true (cold path, round 6): the samples of the mask `heavy` are cut as zeros -- they go round the fixed-point form
+        // (heavy_add below)
+        auto digitise = [&](int lane, int dst_bytes, auto heavy_tag, unsigned heavy) -> bool {
+            constexpr bool HEAVY = decltype(heavy_tag)::value;
             asm volatile("" : "+v"(lane));  // (addresses recomputed here, not hoisted and parked across the other phases)
             const bool active = lane < NCOL / 2;
             const int it = (NCOL / 2) * wave + (active ? lane : 0);
             const int c = it >> 1, chunk = it & 1;
+            const unsigned hmine = HEAVY ? (heavy >> (16 * chunk)) & 0xFFFFu : 0u;
             const bool cvalid = c < NC;
             const int src = cvalid ? wsrc(c) : 0;
             const int E = Ex[c];
@@ -325,7 +334,8 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                     // mantissa of w 2^(F - E) + magic = 2^51 + 0x808080808080 + I: xor with the constant's own bits leaves
                     // bytes 0..5 = the balanced digits and bits 48..51 = the top digit (4-bit two's complement)
                     const double wv = wsrcp[(4 * g4 + j) * WS];
-                    const double v = __builtin_fma(cvalid ? wv : 0.0, qsc, magic);
+                    const bool take = HEAVY ? cvalid && !((hmine >> (4 * g4 + j)) & 1u) : cvalid;
+                    const double v = __builtin_fma(take ? wv : 0.0, qsc, magic);
                     const unsigned lo = (unsigned)__double2loint(v) ^ 0x80808080u;
                     const unsigned hi = (unsigned)__double2hiint(v) ^ 0x43388080u;
                     bad |= hi;  // any exponent field other than 0x433: the entry does not fit (or is not finite)
@@ -386,6 +396,76 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
             if (!fin || Enew > E9_EMAX) Enew = E9_POISON;
             if (Eold > 5000) Enew = Eold;  // (a poisoned column stays poisoned)
             if (active && chunk == 0) Ex[c] = Enew;
+        };
+
+        // ---- (round 6, cold path) rows far above the scale go ROUND the fixed-point form.  Until round 5 a tile with an entry that did
+        // not fit raised its columns' exponents for the rest of the workgroup's run: an outlier row -- a sample 1e6 x its neighbours,
+        // a heavy sample weight -- had every later row cut far below its own resolution, the W-side guard then sent the workgroup's
+        // whole slice (39 k rows at N = 10 M) to the fp64 engine: 10 such rows per million halved the rate.  Now the rows of the tile
+        // that do not fit are found (heavy_bits: per (column, 16-sample chunk) item the samples whose entry leaves the form, OR-ed
+        // over the items in LDS); if they are few and finite the tile is cut again WITHOUT them under the old exponents, and each of
+        // them is added to the fp64 accumulators directly -- w P_i, w z_i, w x 2^(F - E_c), an exact scaling, into the accumulators of
+        // the dimensions the sample observes (heavy_add: the lane's 80 accumulator entries, as emit() maps them).  That is what the
+        // reference's fp64 sums do with such a row (ppca_model.rs:297-306); the dimensions MASKED in it keep their full resolution.
+        // Many such rows in one tile are a change of scale: the exponents rise as before.
+        int *hvw = Ex + NCOL;  // [0] the samples of the tile that do not fit, [1] "cannot go round"
+        auto heavy_bits = [&](int lane) {
+            asm volatile("" : "+v"(lane));
+            const bool active = lane < NCOL / 2;
+            const int it = (NCOL / 2) * wave + (active ? lane : 0);
+            const int c = it >> 1, chunk = it & 1;
+            const bool cvalid = c < NC;
+            const int src = cvalid ? wsrc(c) : 0;
+            const int E = Ex[c];
+            const bool live = active && cvalid && E <= 5000;
+            const double qsc = __hiloint2double((1023 + E9_F - (live ? E : 0)) << 20, 0);
+            const double magic = __hiloint2double(0x43388080, (int)0x80808080);
+            unsigned bits = 0u, nogo = 0u;
+            for (int j = 0; j < 16; ++j) {
+                const double wv = live ? Wcur[(16 * chunk + j) * WS + src] : 0.0;
+                const double v = __builtin_fma(wv, qsc, magic);
+                const unsigned hi = (unsigned)__double2hiint(v) ^ 0x43388080u;
+                if ((hi >> 20) != 0u) {
+                    bits |= 1u << (16 * chunk + j);
+                    // not finite, or so far above the column's scale that w 2^(F - E) would overflow: the exponents have to rise
+                    if (!(__builtin_fabs(wv) < __builtin_inf()) || __builtin_amdgcn_frexp_exp(wv) + E9_F - E > 1000) nogo = 1u;
+                }
+            }
+            if (bits) __hip_atomic_fetch_or(reinterpret_cast<unsigned *>(hvw), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nogo) __hip_atomic_fetch_or(reinterpret_cast<unsigned *>(hvw + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto heavy_add = [&](int lane, unsigned hv, int slot) {
+            asm volatile("" : "+v"(lane));
+            const int l15 = lane & 15, l4 = lane >> 4;
+            unsigned mw[RT][4];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mw[r][q] = Mb[(DW * wave + 16 * r + 4 * l4 + q) * 4 + slot];
+            double sc[NCT];
+            int src[NCT];
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const int c = 16 * t + l15;
+                const int E = Ex[c];
+                sc[t] = (c < NC && E <= 5000) ? __hiloint2double((1023 + E9_F - E) << 20, 0) : 0.0;
+                src[t] = c < NC ? wsrc(c) : 0;
+            }
+            for (unsigned rest = hv; rest != 0u; rest &= rest - 1u) {
+                const int i = __builtin_ctz(rest);                 // sample of the tile (wave-uniform)
+                const int bitpos = 8 * (i >> 3) + 7 - (i & 7);     // its bit in a dimension's sample mask (byte = staging wave, row r at bit 7 - r)
+                double wv[NCT];
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) wv[t] = Wcur[i * WS + src[t]] * sc[t];
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool obs = (mw[r][q] >> bitpos) & 1u;
+#pragma unroll
+                        for (int t = 0; t < NCT; ++t) accM[r][t][q] += obs ? wv[t] : 0.0;
+                    }
+            }
         };
 
         // ---- accumulators -> the workgroup's partial (x 2^(E - F)); C/D row of v_mfma_i32_16x16x64_i8 = 4 (lane / 16) + reg
@@ -498,10 +578,29 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
 #pragma unroll 1
             for (;;) {  // normally one trip
                 ++attempt;
-                const bool bad = !have_scale || digitise(lane, pending ? PG_BYTES : P0_BYTES);
+                const bool bad = !have_scale || digitise(lane, pending ? PG_BYTES : P0_BYTES, std::false_type{}, 0u);
                 if (bad && lane == 0) __hip_atomic_store(vstamp, attempt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 role_barrier(bbar, bbar_target, lane_entry);
-                const bool viol = __builtin_amdgcn_readfirstlane(__hip_atomic_load(vstamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == attempt;
+                bool viol = __builtin_amdgcn_readfirstlane(__hip_atomic_load(vstamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == attempt;
+                bool hv_dirty = false;  // the two words are cleared behind the NEXT barrier of the role (every wave has read them by then)
+                if (viol && have_scale && p.heavy_max > 0) {  // (cold) a few rows above the scale: round the fixed-point form
+                    heavy_bits(lane);
+                    role_barrier(bbar, bbar_target, lane_entry);
+                    const unsigned hv = (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(hvw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const unsigned nogo = (unsigned)__builtin_amdgcn_readfirstlane(__hip_atomic_load(hvw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    hv_dirty = true;
+                    // (a window in which tile after tile has a few such rows -- weights spread over many orders, as in the first
+                    //  iterations of a mixture -- is better served by ONE rise of the exponents than by a second cut of every tile)
+                    if (hv != 0u && nogo == 0u && __builtin_popcount(hv) <= p.heavy_max && hbudget > 0) {
+                        --hbudget;
+                        (void)digitise(lane, pending ? PG_BYTES : P0_BYTES, std::true_type{}, hv);
+                        heavy_add(lane, hv, slot_cur);
+                        role_barrier(bbar, bbar_target, lane_entry);  // (every wave's planes of the tile are cut again)
+                        if (wave == 0 && lane_entry < 2) hvw[lane_entry] = 0;
+                        hv_dirty = false;
+                        viol = false;
+                    }
+                }
                 // What is contracted now: a fitting tile completes its group (or is the last tile: alone); a tile that does
                 // not fit sends what is pending in alone, under the old exponents -- then (cold path) the integers leave
                 // for the partial, the exponents rise and the tile is cut again.
@@ -520,10 +619,12 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                     flushed = 1;
                     groups = 0;
                     n_flush += viol ? 0 : 1;
+                    if (!viol) hbudget = E9_HEAVY_BUDGET;
                 }
                 if (!viol) break;
                 n_rescale += have_scale;
                 role_barrier(bbar, bbar_target, lane_entry);  // every wave has read the old exponents
+                if (hv_dirty && wave == 0 && lane_entry < 2) hvw[lane_entry] = 0;
                 rescale(lane);
                 have_scale = 1;
                 role_barrier(bbar, bbar_target, lane_entry);

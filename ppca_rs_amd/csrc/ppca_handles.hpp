@@ -58,6 +58,7 @@ struct ppca_ctx {
     std::shared_ptr<DevPool> pool;  // block cache behind dev_alloc while USE_CTX(this) is in scope
     bool timing = false;
     int skip_llk = 0;  // internal: set around the mixture's component EM steps (PassArgs::no_llk)
+    int heavy_max = 8;  // PassArgs::heavy_max of this context's EM passes (ppca_ctx_set_heavy_rows)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     BufRef part;  // per-workgroup partial statistics
     size_t part_cap = 0;

@@ -57,6 +57,9 @@ struct PassArgs {
                           // slices (runs of tiles, as the guarded launch dealt them) of the flagged workgroups `who`, each slice
                           // split over gridDim.x / n_flagged workgroups; nullptr: qflag decides as before
     const int *who;       // [n_flagged] (runflag[QF_NFLAGGED - QF_MODE]) ascending workgroup indices of the guarded launch
+    int heavy_max;        // em9_kernel's back role: a tile with at most this many rows that do not fit the fixed-point form of the
+                          // mask-side statistics sends those rows round it (exact fp64 adds) instead of raising its exponents; 0: every
+                          // such tile raises them (rounds 3-5: ppca_ctx_set_heavy_rows, a test hook)
     int skip_qprep;       // the slice table / guard flags / padded C behind qtab are already those of `model` (written by
                           // finalize_qprep_kernel at the end of the previous EM step): the pass launches no qprep_kernel
 };

@@ -23,7 +23,7 @@ def test_header_symbols_exported(hiplib):
     for n in names:
         assert hasattr(hiplib, n), f"{n} declared in include/ppca_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert hiplib.ppca_abi_version() == 5
+    assert hiplib.ppca_abi_version() == 6
 
 
 def test_path_kind_and_stats_len(hiplib):

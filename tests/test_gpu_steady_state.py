@@ -37,9 +37,11 @@ def ctx(P):
 
     c = _lib.default_context()
     c.set_grid_limit(0)
+    c.set_heavy_rows(8)
     c.debug_counters(reset=True)
     yield c
     c.set_grid_limit(0)
+    c.set_heavy_rows(8)
 
 
 def _rel(a, b):
@@ -308,7 +310,10 @@ def test_outlier_row_sends_the_statistics_to_fp64(P, oracle, ctx, k, d):
     grid, 1e-3 .. 1e-2 on one workgroup).  wguard_kernel sees it in the reduced statistics (a diagonal entry of S not
     large against the rounding bound of its column) and the pass is repeated with fp64 accumulation, as the reference sums
     (ppca_model.rs:297-306): every block within 1e-9 of the oracle, dimension by dimension where the large row is masked;
-    the same data without the outlier stays on the int8 engine."""
+    the same data without the outlier stays on the int8 engine.  (Round 6: the eight-wave kernel now sends such a row ROUND its
+    fixed-point form -- test_outlier_rows_go_round_the_fixed_point_form; ppca_ctx_set_heavy_rows(0) restores the behaviour this test
+    is about, the guard behind it.)"""
+    ctx.set_heavy_rows(0)
     n = 6000
     rng = np.random.default_rng(3)
     x, _, _ = oracle.synth(n, d, k, 0.3, 11)
@@ -351,6 +356,7 @@ def test_outlier_rows_cost_their_workgroups_slices(P, oracle, ctx, k):
     two workgroups, 2 x 79 x 32 rows, every block within 1e-9 of the literal oracle (ppca_model.rs:277-358) -- un-weighted,
     weighted (the list carries the rows' weights) and as a GATHERED component pass of the mixture (the list composes with the
     pass's own gather list); two runs bit-identical; more flagged workgroups than half the grid: the whole pass again."""
+    ctx.set_heavy_rows(0)  # (round 6: by default such rows go round the fixed-point form and the second stage has nothing to do)
     n, d = 20000, 256
     rng = np.random.default_rng(50 + k)
     x, _, _ = oracle.synth(n, d, k, 0.3, 17 + k)
@@ -393,6 +399,66 @@ def test_outlier_rows_cost_their_workgroups_slices(P, oracle, ctx, k):
     got = _stats(P, P.Dataset(xa), m)
     assert ctx.last_fallback()[0] == 1
     _assert_stats(got, oracle.stats(xa, s, c, mu), d, k, 1e-9, (k, "half the grid"))
+
+
+@pytest.mark.parametrize("k,d", [(10, 256), (4, 64), (7, 200)])
+def test_outlier_rows_go_round_the_fixed_point_form(P, oracle, ctx, k, d):
+    """Round 6 (em9_kernel's back role, cold path): the rows of a tile that do not fit the fixed-point form of the mask-side statistics
+    -- samples at 1e6 x their neighbours, a sample weight of 1e9 -- are cut out of the tile's digit planes and added to the fp64
+    accumulators directly, under the old exponents: what the reference's f64 sums do with such a row (ppca_model.rs:297-306).  No
+    exponent rises (counter 0 stays 0), no guard trips, nothing is recomputed; every block within 1e-9 of the oracle and, dimension by
+    dimension where a large row is masked, the diagonal of S too -- on the full grid and on ONE workgroup walking every tile
+    (rounds 3-5 had that workgroup cut every later row at the outlier's scale).  Up to eight such rows in one tile go round; nine are
+    a change of scale: the exponents rise and the guard decides as before."""
+    n = 6000
+    rng = np.random.default_rng(31 + k)
+    x, _, _ = oracle.synth(n, d, k, 0.3, 19)
+    c, mu, s = 0.5 * rng.standard_normal((d, k)), 0.05 * rng.standard_normal(d), 0.7
+    m = P.PPCAModel(s, c, mu)
+    kp = k * (k + 1) // 2
+    diag = [a * (a + 1) // 2 + a for a in range(k)]
+
+    def check(xo, w, rows, tag, expect_round):
+        want = oracle.stats(xo, s, c, mu, w)
+        for cap in (0, 1):
+            ctx.set_grid_limit(cap)
+            ctx.debug_counters(reset=True)
+            got = _stats(P, P.Dataset(xo, w) if w is not None else P.Dataset(xo), m)
+            cnt = ctx.debug_counters()
+            if expect_round:
+                assert ctx.last_guard() == (0, 0) and ctx.last_fallback()[:3] == (0, 0, 0), (tag, cap, ctx.last_guard())
+                assert cnt[0] == 0, (tag, cap, cnt)
+            _assert_stats(got, want, d, k, 1e-9, (k, cap, tag))
+            Sg, Sw = got[d * k:d * k + d * kp].reshape(d, kp), want[d * k:d * k + d * kp].reshape(d, kp)
+            for r in rows:
+                masked = ~np.isfinite(xo[r])
+                if masked.any():
+                    assert (np.abs(Sg[masked][:, diag] - Sw[masked][:, diag]) / np.abs(Sw[masked][:, diag])).max() < 1e-9, (tag, cap, r)
+        ctx.set_grid_limit(0)
+
+    check(x, None, [], "clean", True)
+    xo = x.copy()
+    xo[100] *= 1e6
+    check(xo, None, [100], "one row", True)
+    xo = x.copy()
+    rows = [64, 65, 70, 77, 80, 90, 94, 95, 3000, 5999]  # eight in one tile, the last row of the dataset
+    for r in rows:
+        xo[r] *= 10.0 ** rng.uniform(4, 8)
+    check(xo, None, rows, "eight in a tile", True)
+    w = rng.uniform(0.5, 2.0, n)
+    w[1234] = 1e9
+    w[17] = 1e-9
+    check(x, w, [1234], "heavy weight", True)
+    xo = x.copy()
+    for r in range(128, 137):  # nine rows of one tile: a change of scale -- exponents rise, the guard behind them decides
+        xo[r] *= 1e6
+    check(xo, None, list(range(128, 137)), "nine in a tile", False)
+    # an EM step on the outlier data agrees with the oracle's noise level (the row systems there have condition ~1e12)
+    xo = x.copy()
+    xo[100] *= 1e6
+    s1, _, _ = oracle.iterate(xo, s, c, mu)
+    new = m.iterate(P.Dataset(xo))
+    assert abs(new.isotropic_noise - s1) < 1e-9 * s1 and np.isfinite(new.transform).all()
 
 
 def test_slice_table_is_cached_per_model_content(P, oracle, ctx):
