@@ -368,20 +368,32 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         };
 
         // ---- new exponents from the current tile's column maxima (cold path)
-        auto rescale = [&](int lane) {
+        // robust (round 6: the workgroup's FIRST scale, when rows may go round the form): the smallest non-zero maximum over the
+        // tile's four groups of eight samples instead of the maximum over all 32 -- an outlier row in the scale-setting tile then
+        // does not set the scale; it does not fit it and goes round like any later one (if that leaves more than heavy_max rows
+        // outside, the next attempt raises the exponents from the plain maximum)
+        auto rescale = [&](int lane, bool robust) {
             asm volatile("" : "+v"(lane));
             const bool active = lane < NCOL / 2;
             const int it = (NCOL / 2) * wave + (active ? lane : 0);
             const int c = it >> 1, chunk = it & 1;
             const bool cvalid = c < NC;
             const int src = cvalid ? wsrc(c) : 0;
-            double m = 0.0;
+            double m = 0.0, mg[2] = {0.0, 0.0};
             bool fin = true;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const double av = __builtin_fabs(cvalid ? Wcur[(16 * chunk + j) * WS + src] : 0.0);
                 fin = fin && (av < __builtin_inf());
                 m = __builtin_fmax(m, av);
+                mg[j >> 3] = __builtin_fmax(mg[j >> 3], av);
+            }
+            if (robust) {
+                const double big = __builtin_inf();
+                double lo = __builtin_fmin(mg[0] > 0.0 ? mg[0] : big, mg[1] > 0.0 ? mg[1] : big);
+                lo = __builtin_fmin(lo, dpp_f64<0xB1, 0xF>(lo));
+                const double mx = __builtin_fmax(m, dpp_f64<0xB1, 0xF>(m));
+                m = lo < big ? lo : mx;
             }
             m = __builtin_fmax(m, dpp_f64<0xB1, 0xF>(m));  // the other chunk of the column sits in the neighbouring lane
             const int finw = __builtin_amdgcn_update_dpp(0, fin ? 1 : 0, 0xB1, 0xF, 0xF, true);
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
                 n_rescale += have_scale;
                 role_barrier(bbar, bbar_target, lane_entry);  // every wave has read the old exponents
                 if (hv_dirty && wave == 0 && lane_entry < 2) hvw[lane_entry] = 0;
-                rescale(lane);
+                rescale(lane, !have_scale && p.heavy_max > 0);
                 have_scale = 1;
                 role_barrier(bbar, bbar_target, lane_entry);
             }
