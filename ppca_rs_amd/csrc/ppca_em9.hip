@@ -368,10 +368,10 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
         };
 
         // ---- new exponents from the current tile's column maxima (cold path)
-        // robust (round 6: the workgroup's FIRST scale, when rows may go round the form): the smallest non-zero maximum over the
-        // tile's four groups of eight samples instead of the maximum over all 32 -- an outlier row in the scale-setting tile then
-        // does not set the scale; it does not fit it and goes round like any later one (if that leaves more than heavy_max rows
-        // outside, the next attempt raises the exponents from the plain maximum)
+        // robust (round 6: the workgroup's FIRST scale, when rows may go round the form): per column the largest magnitude that at
+        // least `heavy_max` of the tile's 32 entries exceed -- the (heavy_max + 1)-th largest -- instead of the largest: outlier rows in
+        // the scale-setting tile then do not set the scale; they do not fit it and go round like any later one.  (Clean rows: the
+        // entries above it are within the form's 2^HEAD of headroom.  Fewer than heavy_max + 1 non-zero entries: the plain maximum.)
         auto rescale = [&](int lane, bool robust) {
             asm volatile("" : "+v"(lane));
             const bool active = lane < NCOL / 2;
@@ -379,21 +379,29 @@ __global__ __launch_bounds__(512) void em9_kernel(PassArgs p) {
             const int c = it >> 1, chunk = it & 1;
             const bool cvalid = c < NC;
             const int src = cvalid ? wsrc(c) : 0;
-            double m = 0.0, mg[2] = {0.0, 0.0};
+            double m = 0.0;
             bool fin = true;
+            if (!robust) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double av = __builtin_fabs(cvalid ? Wcur[(16 * chunk + j) * WS + src] : 0.0);
-                fin = fin && (av < __builtin_inf());
-                m = __builtin_fmax(m, av);
-                mg[j >> 3] = __builtin_fmax(mg[j >> 3], av);
-            }
-            if (robust) {
-                const double big = __builtin_inf();
-                double lo = __builtin_fmin(mg[0] > 0.0 ? mg[0] : big, mg[1] > 0.0 ? mg[1] : big);
-                lo = __builtin_fmin(lo, dpp_f64<0xB1, 0xF>(lo));
-                const double mx = __builtin_fmax(m, dpp_f64<0xB1, 0xF>(m));
-                m = lo < big ? lo : mx;
+                for (int j = 0; j < 16; ++j) {
+                    const double av = __builtin_fabs(cvalid ? Wcur[(16 * chunk + j) * WS + src] : 0.0);
+                    fin = fin && (av < __builtin_inf());
+                    m = __builtin_fmax(m, av);
+                }
+            } else {  // (cold: once per workgroup)
+                const int hm = p.heavy_max;
+                double cand = 0.0, mx = 0.0;
+                for (int j = 0; j < 16; ++j) {
+                    const double av = __builtin_fabs(cvalid ? Wcur[(16 * chunk + j) * WS + src] : 0.0);
+                    fin = fin && (av < __builtin_inf());
+                    mx = __builtin_fmax(mx, av);
+                    int above = 0;  // entries of the column (both chunks) strictly above this one
+                    for (int i = 0; i < 32; ++i) above += __builtin_fabs(cvalid ? Wcur[i * WS + src] : 0.0) > av ? 1 : 0;
+                    if (above >= hm) cand = __builtin_fmax(cand, av);
+                }
+                cand = __builtin_fmax(cand, dpp_f64<0xB1, 0xF>(cand));
+                mx = __builtin_fmax(mx, dpp_f64<0xB1, 0xF>(mx));
+                m = cand > 0.0 ? cand : mx;
             }
             m = __builtin_fmax(m, dpp_f64<0xB1, 0xF>(m));  // the other chunk of the column sits in the neighbouring lane
             const int finw = __builtin_amdgcn_update_dpp(0, fin ? 1 : 0, 0xB1, 0xF, 0xF, true);
