@@ -338,6 +338,10 @@ extern "C" int ppca_ctx_create(int32_t device_id, void *stream, ppca_ctx **out) 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     ctx->n_cu_device = ctx->n_cu;
+    if (const char *e = getenv("PPCA_HEAVY_ROWS")) {  // (A/B runs: the initial value of ppca_ctx_set_heavy_rows)
+        const int v = atoi(e);
+        ctx->heavy_max = v < 0 ? 0 : (v > 32 ? 32 : v);
+    }
     if (stream) {
         ctx->stream = static_cast<hipStream_t>(stream);
     } else {
