@@ -765,6 +765,7 @@ static int qtab_layout(ppca_ctx *ctx, PassArgs &a) {
         HIP_TRY(hipMemsetAsync(a.qflag, 0, sizeof(int) * 16, ctx->stream));
         ctx->qtab_base = ctx->qtab->p;
         ctx->qtab_model = nullptr;
+        ctx->guard_words.clear();  // (they pointed into the previous block)
     }
     return PPCA_OK;
 }
@@ -861,6 +862,7 @@ static int em_accumulate_impl(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model 
     }
     HIP_TRY(launch_pass_em(model->k, grid, a, ctx->stream));
     qtab_commit(ctx, model, fused_gram_mode() != 1);  // (the fp64-pinned engine launches no qprep_kernel)
+    ctx->guard_words.assign(1, a.qflag);
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(e1, ctx->stream));
         ctx->events.emplace_back(e0, e1);
@@ -1334,6 +1336,7 @@ static int mix_tables(ppca_ctx *ctx, ppca_model *const *models, int nm, void **t
     if (ctx->mixq->p != ctx->mixq_base) {  // a new block: the guard words start at zero (the ticket counters of the reductions)
         HIP_TRY(hipMemsetAsync(ctx->mixq->p, 0, stride * MIX_MAX, ctx->stream));
         ctx->mixq_base = ctx->mixq->p;
+        ctx->guard_words.clear();
         ctx->mixq_slots.assign(MIX_MAX, std::make_pair((const void *)nullptr, (uint64_t)0));
     }
     bool stale = false;
@@ -1631,6 +1634,8 @@ static int mix_em_step_multi(ppca_ctx *ctx, ppca_comm *comm, ppca_dataset *ds, p
     }
     // 4. reductions + verdicts in one launch, then the (normally idle) second stages
     HIP_TRY(launch_reduce_wguard_multi(k, r, grid, ctx->stream));
+    ctx->guard_words.clear();
+    for (int c = 0; c < nm; ++c) ctx->guard_words.push_back(r.g[c].qflag);
     for (int c = 0; c < nm; ++c)
         HIP_TRY(launch_em_fallback(k, grid, pa[c], r.g[c], r.part[c], part2, len, r.out[c], ctx->stream));
     if (comm) {
@@ -1913,33 +1918,40 @@ extern "C" int ppca_ctx_set_heavy_rows(ppca_ctx *ctx, int32_t max_rows) {
 extern "C" int ppca_em_last_guard(ppca_ctx *ctx, int32_t *gram_unsafe, int32_t *stats_unsafe) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "null context");
     USE_CTX(ctx);
-    int flags[16] = {0};
-    if (ctx->qtab) {
-        PassArgs a{};
-        fused_qtab_layout(ctx->qtab->p, a);
-        HIP_TRY(hipMemcpyAsync(flags, a.qflag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
     // (the verdicts reduce_wguard_kernel filed for the PASS: the tile flags themselves may already be the next model's --
-    //  finalize_qprep_kernel builds its table at the end of the step)
-    if (gram_unsafe) *gram_unsafe = flags[QF_GVERDICT];
-    if (stats_unsafe) *stats_unsafe = flags[QF_WVERDICT];
+    //  finalize_qprep_kernel builds its table at the end of the step.  After a multi-component mixture step: OR over its K passes.
+    //  With a pinned engine -- PPCA_GRAM_FP64=1, tuning builds -- nothing files a verdict: both read 0.)
+    int g = 0, w = 0;
+    std::vector<int> flags(16 * std::max<size_t>(1, ctx->guard_words.size()), 0);
+    for (size_t i = 0; i < ctx->guard_words.size(); ++i)
+        HIP_TRY(hipMemcpyAsync(flags.data() + 16 * i, ctx->guard_words[i], sizeof(int) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->guard_words.size(); ++i) {
+        g |= flags[16 * i + QF_GVERDICT];
+        w |= flags[16 * i + QF_WVERDICT];
+    }
+    if (gram_unsafe) *gram_unsafe = g;
+    if (stats_unsafe) *stats_unsafe = w;
     return PPCA_OK;
 }
 
 extern "C" int ppca_em_last_fallback(ppca_ctx *ctx, int32_t *mode, int32_t *workgroups, int64_t *rows, double *stage_ms) {
     if (!ctx) return fail(PPCA_ERR_INVALID, "null context");
     USE_CTX(ctx);
-    int flags[16] = {0};
-    if (ctx->qtab) {
-        PassArgs a{};
-        fused_qtab_layout(ctx->qtab->p, a);
-        HIP_TRY(hipMemcpyAsync(flags, a.qflag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    std::vector<int> flags(16 * std::max<size_t>(1, ctx->guard_words.size()), 0);
+    for (size_t i = 0; i < ctx->guard_words.size(); ++i)
+        HIP_TRY(hipMemcpyAsync(flags.data() + 16 * i, ctx->guard_words[i], sizeof(int) * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (mode) *mode = flags[QF_MODE];
-    if (workgroups) *workgroups = flags[QF_NFLAGGED];
-    if (rows) *rows = flags[QF_NROWS2];
+    int md = 0, wg = 0;
+    int64_t rw = 0;
+    for (size_t i = 0; i < ctx->guard_words.size(); ++i) {  // (a multi-component mixture step: the largest mode, the sums over its K passes)
+        md = std::max(md, flags[16 * i + QF_MODE]);
+        wg += flags[16 * i + QF_NFLAGGED];
+        rw += flags[16 * i + QF_NROWS2];
+    }
+    if (mode) *mode = md;
+    if (workgroups) *workgroups = wg;
+    if (rows) *rows = rw;
     double tot = 0.0;
     for (auto &ev : ctx->events2) {
         float ms = 0.f;

@@ -59,6 +59,8 @@ struct ppca_ctx {
     bool timing = false;
     int skip_llk = 0;  // internal: set around the mixture's component EM steps (PassArgs::no_llk)
     int heavy_max = 8;  // PassArgs::heavy_max of this context's EM passes (ppca_ctx_set_heavy_rows)
+    std::vector<const int *> guard_words;  // the guard words (PassArgs::qflag) of the context's LAST fused EM pass -- or of the K component
+                                           // passes of its last multi-component mixture step: ppca_em_last_guard / _fallback read these
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     BufRef part;  // per-workgroup partial statistics
     size_t part_cap = 0;
