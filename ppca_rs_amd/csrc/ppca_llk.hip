@@ -345,9 +345,11 @@ struct CfgL8 {
     static constexpr int OFF_C = OFF_X + B * XS;
     static constexpr int OFF_G = OFF_C + DP * CS;
     static constexpr int OFF_B1 = OFF_G + 2 * B * GS;
-    static constexpr int OFF_M = OFF_B1 + 3 * 2 * B * BS;  // mask words of the round's two tiles, 2 B x 4 u64
-    static constexpr int OFF_XX = OFF_M + 2 * B * 4;       // |x~|^2 of the 2 B samples
-    static constexpr int OFF_MU = OFF_XX + 2 * B;          // the mean (DP doubles, zero past d): re-read by the staging of every tile
+    // mask words and |x~|^2 of the round's two tiles -- and a SECOND copy for the round's first tile (block 2): the first tile of round
+    // r + 1 is staged while the solver step of round r still reads round r's (round 6); block of (slot, parity): see stage_tile
+    static constexpr int OFF_M = OFF_B1 + 3 * 2 * B * BS;  // 3 B x 4 u64
+    static constexpr int OFF_XX = OFF_M + 3 * B * 4;       // 3 B
+    static constexpr int OFF_MU = OFF_XX + 3 * B;          // the mean (DP doubles, zero past d): re-read by the staging of every tile
     static constexpr int LDS_DOUBLES = OFF_MU + DP;
     static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (llk8)");
 };
@@ -450,7 +452,8 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
     load_table();
     const double qs = gram_wave ? p.qscale[16 * ct + (lane_entry & 15)] : 0.0;
 
-    auto stage_tile = [&](int lane, int slot) {
+    auto stage_tile = [&](int lane, int slot, int par) {
+        const int mr = slot == 1 ? B : (par ? 2 * B : 0);  // block of the tile's mask words / |x~|^2
         // the lane's four means and limits (observed <=> |x| < lim: +inf for a real dimension, -1 past d), rebuilt per tile from
         // the LDS copy of the mean: as loop invariants they would sit in 16 registers across the solver step
         double mu[4], lim[4];
@@ -481,10 +484,11 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             pxx[r] = xt[0] * xt[0] + xt[1] * xt[1] + xt[2] * xt[2] + xt[3] * xt[3];
         });
         const unsigned long long myw = ((unsigned long long)(unsigned)st_whi << 32) | (unsigned)st_wlo;
-        if (lane < 4 * RPW) Ms[(slot * B + wave * RPW) * 4 + lane] = myw;
-        store_row_sums4(pxx, lane, xxs + slot * B + wave * RPW);
+        if (lane < 4 * RPW) Ms[(mr + wave * RPW) * 4 + lane] = myw;
+        store_row_sums4(pxx, lane, xxs + mr + wave * RPW);
     };
-    auto contract_tile = [&](int lane, int slot) {
+    auto contract_tile = [&](int lane, int slot, int par) {
+        const int mr = slot == 1 ? B : (par ? 2 * B : 0);
         const int l15 = lane & 15, l4 = lane >> 4;
         // b = X~ C on v_mfma_f64_4x4x4 (four independent 4 x 4 x 4 blocks per instruction: block b = lane bits 2-3 = samples
         // 4 b .. 4 b + 3 of the row tile; A[i][k] in lane 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane
@@ -503,7 +507,7 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
         const double *cpc = Cs + (DPQ * kq + l4) * CS;
         unsigned long long mwd[4];
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) mwd[kc] = Ms[(slot * B + 16 * rt + l15) * 4 + kc];
+        for (int kc = 0; kc < 4; ++kc) mwd[kc] = Ms[(mr + 16 * rt + l15) * 4 + kc];
         {
             constexpr int CH = 2;
             double axb[2][CH], cbb[2][CH][NCB];
@@ -571,33 +575,47 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
         }
     };
 
+    // Round r: [its first tile was staged during round r - 1's solver step] contract A, stage B, contract B, then the solver step of
+    // the round's 64 samples on wave 0 WHILE the other seven waves stage the first tile of round r + 1 (wave 0 stages its four rows
+    // behind its solver step).  Until round 6 the other waves stood at the barrier during the solver step (a sixth of the round by
+    // ablation, LLK8_EXP_NOSOLVE: 2.36 -> 1.97 ms at N = 4 M) and everybody staged the first tile afterwards (another sixth,
+    // LLK8_EXP_NOSTAGE0: 1.98 ms).
     double run_llk = 0.0, run_w = 0.0;
+    int par = 0;  // which copy of the first tile's mask words / |x~|^2 the round reads
     if (tile_begin < tile_end) load_tile(tile_begin);
+    __syncthreads();
+    if (tile_begin < tile_end) {
+        stage_tile(lane_entry, 0, par);
+        load_tile(tile_begin + 1);
+    }
     __syncthreads();
     for (int64_t tile = tile_begin; tile < tile_end; tile += 2) {
         int lane = lane_entry;
         asm volatile("" : "+v"(lane));
-        stage_tile(lane, 0);
-        load_tile(tile + 1);
+        contract_tile(lane, 0, par);
         __syncthreads();
-        contract_tile(lane, 0);
-        __syncthreads();
-        stage_tile(lane, 1);
+        stage_tile(lane, 1, par);
         load_tile(tile + 2);
         __syncthreads();
-        contract_tile(lane, 1);
+        contract_tile(lane, 1, par);
         __syncthreads();
+        const bool more = tile + 2 < tile_end;  // (wave-uniform)
+#ifdef LLK8_EXP_NOSOLVE  // (timing experiment, results wrong: the round without its one-wave solver step)
+        if (false) {
+#else
         if (wave == 0) {
+#endif
             const int slot = lane >> 5, i = lane & (B - 1);
+            const int mrs = slot == 1 ? B : (par ? 2 * B : 0);
             const int64_t t = tile + slot;
             const int64_t row = t * B + i;
             const bool mine = t < tile_end && row < n;
             const double *g0 = Gs + lane * GS;
             const double *b1 = B1 + lane * BS;
             const double wgt = mine ? (p.w ? p.w[row] : 1.0) : 0.0;
-            const unsigned long long *mw = Ms + lane * 4;
+            const unsigned long long *mw = Ms + (mrs + i) * 4;
             const int m = __popcll(mw[0]) + __popcll(mw[1]) + __popcll(mw[2]) + __popcll(mw[3]);
-            const double xx = xxs[lane];
+            const double xx = xxs[mrs + i];
             Posterior<K> post;
             double pm;
             int pe;
@@ -619,6 +637,12 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                 (void)xx; (void)m; (void)wgt; (void)pm; (void)pe;
             }
         }
+#ifndef LLK8_EXP_NOSTAGE0  // (timing experiment, results wrong: the rounds without the staging of their first tile)
+        if (more) {  // the first tile of the next round (its rows have been in registers since this round's second staging)
+            stage_tile(lane, 0, par ^ 1);
+            load_tile(tile + 3);
+        }
+#endif
         if constexpr (OUT != 0) {
             __syncthreads();
             // (a fresh opaque copy of the lane index: everything the phase derives from it -- addresses, the re-read of the rows -- is computed
@@ -681,7 +705,8 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
 #pragma unroll
                     for (int h = H0; h < H1; ++h) {
                         if constexpr (OUT == 2) {
-                            const unsigned long long w0 = Ms[si * 4 + 2 * h], w1 = Ms[si * 4 + 2 * h + 1];
+                            const int mro = (si >> 5) ? B : (par ? 2 * B : 0);
+                            const unsigned long long w0 = Ms[(mro + (si & (B - 1))) * 4 + 2 * h], w1 = Ms[(mro + (si & (B - 1))) * 4 + 2 * h + 1];
                             const double x0 = __longlong_as_double(((long long)ov[r][h][1] << 32) | ov[r][h][0]);
                             const double x1 = __longlong_as_double(((long long)ov[r][h][3] << 32) | ov[r][h][2]);
                             o[h][0] = ((w0 >> lo) & 1ull) ? x0 : o[h][0];
@@ -715,6 +740,7 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             }
         }
         __syncthreads();
+        par ^= 1;
     }
     if (wave == 0 && scal) {
         const double v2 = wave_sum(run_llk), v3 = wave_sum(run_w);
