@@ -350,13 +350,17 @@ struct CfgL8 {
     static constexpr int OFF_M = OFF_B1 + 3 * 2 * B * BS;  // 3 B x 4 u64
     static constexpr int OFF_XX = OFF_M + 3 * B * 4;       // 3 B
     static constexpr int OFF_MU = OFF_XX + 3 * B;          // the mean (DP doubles, zero past d): re-read by the staging of every tile
-    static constexpr int LDS_DOUBLES = OFF_MU + DP;
+    static constexpr int OFF_FLAG = OFF_MU + DP;           // hand-off counter of the solver wave's rows (llk8_run)
+    static constexpr int LDS_DOUBLES = OFF_FLAG + 2;
     static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (llk8)");
 };
 
 // Four per-lane partial sums (one register per row of a wave's four staged rows) -> the four row totals into out[0..3]
 // (store_row_sums for four rows): halves, then 16-lane rows, then four DPP steps.
-__device__ __forceinline__ void store_row_sums4(const double (&pxx)[4], int lane, double *out) {
+// only < 0: all four rows are stored; otherwise only row `only` (the others' registers hold zeros: llk8_run's hand-off of the solver
+// wave's rows, one to each of four other waves -- the SAME tree of additions for the row as when its own wave sums it with its three
+// neighbours, so a sample's |x~|^2 does not depend on who staged it)
+__device__ __forceinline__ void store_row_sums4(const double (&pxx)[4], int lane, double *out, int only = -1) {
     const double u0 = fold_halves(pxx[0], pxx[1]);  // lanes 0-31: row 0, lanes 32-63: row 1
     const double u1 = fold_halves(pxx[2], pxx[3]);  // lanes 0-31: row 2, lanes 32-63: row 3
     double v = fold_rows(u0, u1);                   // 16-lane row rho holds data row: 0 -> 0, 1 -> 2, 2 -> 1, 3 -> 3
@@ -365,8 +369,8 @@ __device__ __forceinline__ void store_row_sums4(const double (&pxx)[4], int lane
     v += dpp_f64<0x141, 0xF>(v);
     v += dpp_f64<0x140, 0xF>(v);
     if ((lane & 15) == 0) {
-        const int rho = lane >> 4;
-        out[2 * (rho & 1) + (rho >> 1)] = v;
+        const int rho = lane >> 4, row = 2 * (rho & 1) + (rho >> 1);
+        if (only < 0 || row == only) out[row] = v;
     }
 }
 
@@ -405,6 +409,8 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
         Cs[idx] = (j < d && a < K) ? mC[(int64_t)j * K + a] : 0.0;
     }
     for (int idx = tid; idx < cfg::DP; idx += 512) sm[cfg::OFF_MU + idx] = idx < d ? mMean[idx] : 0.0;
+    unsigned *hand = reinterpret_cast<unsigned *>(sm + cfg::OFF_FLAG);
+    if (tid == 0) *hand = 0u;
 
     const int64_t nleft = n - tile_begin * B;
     const int nrel = (int)(nleft < (1 << 30) ? nleft : (1 << 30));
@@ -575,6 +581,34 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
         }
     };
 
+    // One row of the x~ tile that holds RAW values (the solver wave's hand-off): centred, masked and filed exactly as stage_tile does
+    // it for the row's own wave; r4 = the row's place among that wave's four.
+    auto stage_one = [&](int lane, int ri, int r4, int mr) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t m0 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 2 * lane);
+        const d2_t m1 = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 + 2 * lane);
+        const double mu[4] = {m0[0], m0[1], m1[0], m1[1]};
+        const d2_t v0 = *reinterpret_cast<const d2_t *>(Xs + ri * XS + 2 * lane);
+        const d2_t v1 = *reinterpret_cast<const d2_t *>(Xs + ri * XS + 128 + 2 * lane);
+        const double v[4] = {v0[0], v0[1], v1[0], v1[1]};
+        double xt[4];
+        unsigned long long bal[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double lim = (128 * (q >> 1) + 2 * lane + (q & 1) < d) ? __builtin_inf() : -1.0;
+            const bool ob = __builtin_fabs(v[q]) < lim;
+            xt[q] = ob ? v[q] - mu[q] : 0.0;
+            bal[q] = __builtin_amdgcn_ballot_w64(ob);
+        }
+        *reinterpret_cast<d2_t *>(Xs + ri * XS + 2 * lane) = d2_t{xt[0], xt[1]};
+        *reinterpret_cast<d2_t *>(Xs + ri * XS + 128 + 2 * lane) = d2_t{xt[2], xt[3]};
+        if (lane < 4) Ms[(mr + ri) * 4 + lane] = lane == 0 ? bal[0] : lane == 1 ? bal[1] : lane == 2 ? bal[2] : bal[3];
+        const double px = xt[0] * xt[0] + xt[1] * xt[1] + xt[2] * xt[2] + xt[3] * xt[3];
+        const double pxx[4] = {r4 == 0 ? px : 0.0, r4 == 1 ? px : 0.0, r4 == 2 ? px : 0.0, r4 == 3 ? px : 0.0};
+        store_row_sums4(pxx, lane, xxs + mr + (ri - r4), r4);
+    };
+    unsigned handed = 0u;  // rounds whose solver wave has handed its rows of the next first tile over
+
     // Round r: [its first tile was staged during round r - 1's solver step] contract A, stage B, contract B, then the solver step of
     // the round's 64 samples on wave 0 WHILE the other seven waves stage the first tile of round r + 1 (wave 0 stages its four rows
     // behind its solver step).  Until round 6 the other waves stood at the barrier during the solver step (a sixth of the round by
@@ -605,6 +639,17 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
 #else
         if (wave == 0) {
 #endif
+            if (more) {  // this wave's four rows of the next round's first tile: RAW into the (free) x~ tile, one for each of waves 1..4
+                typedef double d2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    *reinterpret_cast<d2_t *>(Xs + r * XS + 2 * lane) = d2_t{xr[r][0], xr[r][1]};
+                    *reinterpret_cast<d2_t *>(Xs + r * XS + 128 + 2 * lane) = d2_t{xr[r][2], xr[r][3]};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(hand, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                load_tile(tile + 3);
+            }
             const int slot = lane >> 5, i = lane & (B - 1);
             const int mrs = slot == 1 ? B : (par ? 2 * B : 0);
             const int64_t t = tile + slot;
@@ -639,8 +684,20 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
         }
 #ifndef LLK8_EXP_NOSTAGE0  // (timing experiment, results wrong: the rounds without the staging of their first tile)
         if (more) {  // the first tile of the next round (its rows have been in registers since this round's second staging)
-            stage_tile(lane, 0, par ^ 1);
-            load_tile(tile + 3);
+            ++handed;
+            if (wave != 0) {
+                stage_tile(lane, 0, par ^ 1);
+                load_tile(tile + 3);
+                if (wave <= RPW) {  // ... and one of the solver wave's rows
+                    for (;;) {
+                        const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(hand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        if ((int)(seen - handed) >= 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    asm volatile("" ::: "memory");
+                    stage_one(lane, wave - 1, wave - 1, par ? 0 : 2 * B);
+                }
+            }
         }
 #endif
         if constexpr (OUT != 0) {
