@@ -1229,6 +1229,9 @@ extern "C" int ppca_llk(ppca_ctx *ctx, ppca_dataset *ds, const ppca_model *model
         HIP_TRY(hipMemcpyAsync(per_sample_host, l->p, sizeof(double) * (size_t)ds->n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (total_host) *total_host = h[SC_LLK];
+    if (getenv("PPCA_LLK8_TIMING"))  // (meaningful with a -DLLK8_TIMING build of ppca_llk.hip only: cycle sums over the workgroups)
+        fprintf(stderr, "[llk8 cycles, sum over workgroups] contractions %.4g  second staging %.4g  hand-off+solver+table %.4g  last barrier %.4g  other barriers %.4g | wave 1: overlapped staging %.4g\n",
+                h[SC_SQERR], h[SC_DEVSQ], h[SC_NONEMPTY], h[5], h[6], h[7]);
     return PPCA_OK;
 }
 

@@ -435,6 +435,20 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             }
         }
     };
+    // (round 6) One dword of every 128-byte line of the wave's four rows of a tile, a round before the rows themselves are requested:
+    // since the first tile of round r + 1 is staged in round r's solver phase its rows are wanted a solver step EARLIER than before,
+    // and the register set that receives them is free only one contraction ahead -- less than an HBM round trip (the phase table
+    // showed wave 0 standing ~4 k cycles at its hand-off).  The touch brings the lines into the XCD's L2 (one instruction, one
+    // register whose value only keeps the load alive); the 16-byte requests that follow are L2 hits.
+    int pf_acc = 0;
+    auto touch_tile = [&](int64_t tile) {
+        const int rel0 = (int)(tile - tile_begin) * B;
+        int cnt = nrel - rel0;
+        cnt = __builtin_amdgcn_readfirstlane(cnt < 0 ? 0 : (cnt > B ? B : cnt));
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(Xwg + (int64_t)rel0 * p.ldx), 0, cnt * rowbytes, 0x00020000);
+        pf_acc |= (int)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, lane_entry * 128, wave * RPW * rowbytes, 0);
+    };
     // wave unit of the Gram: packed-column tile ct, row tile rt; of b: row tile rtb, quarter kq of the dimensions
     const int ct = wave & 3, rt = wave >> 2;
     const int rtb = wave & 1, kq = wave >> 1;
@@ -614,6 +628,12 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
     // behind its solver step).  Until round 6 the other waves stood at the barrier during the solver step (a sixth of the round by
     // ablation, LLK8_EXP_NOSOLVE: 2.36 -> 1.97 ms at N = 4 M) and everybody staged the first tile afterwards (another sixth,
     // LLK8_EXP_NOSTAGE0: 1.98 ms).
+#ifdef LLK8_TIMING  // (diagnostic build: per-phase cycle sums of wave 0 -- and the overlapped staging of wave 1 -- into the scalars)
+    long long tq[6] = {0, 0, 0, 0, 0, 0}, tl = clock64();
+#define L8_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const long long tn = clock64(); tq[i] += tn - tl; tl = tn; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define L8_STAMP(i)
+#endif
     double run_llk = 0.0, run_w = 0.0;
     int par = 0;  // which copy of the first tile's mask words / |x~|^2 the round reads
     if (tile_begin < tile_end) load_tile(tile_begin);
@@ -626,19 +646,26 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
     for (int64_t tile = tile_begin; tile < tile_end; tile += 2) {
         int lane = lane_entry;
         asm volatile("" : "+v"(lane));
+        L8_STAMP(5)
+#ifndef LLK8_NO_TOUCH
+        touch_tile(tile + 2);
+        touch_tile(tile + 3);
+#endif
         contract_tile(lane, 0, par);
+        L8_STAMP(0)
         __syncthreads();
+        L8_STAMP(4)
         stage_tile(lane, 1, par);
         load_tile(tile + 2);
+        L8_STAMP(1)
         __syncthreads();
+        L8_STAMP(4)
         contract_tile(lane, 1, par);
+        L8_STAMP(0)
         __syncthreads();
+        L8_STAMP(4)
         const bool more = tile + 2 < tile_end;  // (wave-uniform)
-#ifdef LLK8_EXP_NOSOLVE  // (timing experiment, results wrong: the round without its one-wave solver step)
-        if (false) {
-#else
         if (wave == 0) {
-#endif
             if (more) {  // this wave's four rows of the next round's first tile: RAW into the (free) x~ tile, one for each of waves 1..4
                 typedef double d2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -650,6 +677,11 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                 if (lane == 0) __hip_atomic_fetch_add(hand, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 load_tile(tile + 3);
             }
+#ifdef LLK8_EXP_NOSOLVE  // (timing experiment, results wrong: the round without the arithmetic of its one-wave solver step)
+          if (p.d < 0) {
+#else
+          {
+#endif
             const int slot = lane >> 5, i = lane & (B - 1);
             const int mrs = slot == 1 ? B : (par ? 2 * B : 0);
             const int64_t t = tile + slot;
@@ -672,7 +704,9 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                 run_w += wgt;
                 if (p.llks && mine) p.llks[row] = lk;
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef LLK8_EXP_NORELOAD  // (timing experiment, results wrong: the solver wave keeps a stale table slice)
                 load_table();
+#endif
             } else {
                 double z[K], quad, zz;
                 post.solve([&](int a) { return ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; }, z, quad, zz);
@@ -681,6 +715,7 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                 for (int a = 0; a < K; ++a) zr[a] = z[a];
                 (void)xx; (void)m; (void)wgt; (void)pm; (void)pe;
             }
+          }
         }
 #ifndef LLK8_EXP_NOSTAGE0  // (timing experiment, results wrong: the rounds without the staging of their first tile)
         if (more) {  // the first tile of the next round (its rows have been in registers since this round's second staging)
@@ -688,18 +723,24 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             if (wave != 0) {
                 stage_tile(lane, 0, par ^ 1);
                 load_tile(tile + 3);
-                if (wave <= RPW) {  // ... and one of the solver wave's rows
+#ifndef LLK8_HAND_WAVES
+#define LLK8_HAND_WAVES 0x4321  // nibble r: the wave that stages row r of the solver wave
+#endif
+                const int hrow = wave == ((LLK8_HAND_WAVES >> 0) & 15) ? 0 : wave == ((LLK8_HAND_WAVES >> 4) & 15) ? 1
+                               : wave == ((LLK8_HAND_WAVES >> 8) & 15) ? 2 : wave == ((LLK8_HAND_WAVES >> 12) & 15) ? 3 : -1;
+                if (hrow >= 0) {  // ... and one of the solver wave's rows
                     for (;;) {
                         const unsigned seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(hand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                         if ((int)(seen - handed) >= 0) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
                     asm volatile("" ::: "memory");
-                    stage_one(lane, wave - 1, wave - 1, par ? 0 : 2 * B);
+                    stage_one(lane, hrow, hrow, par ? 0 : 2 * B);
                 }
             }
         }
 #endif
+        L8_STAMP(2)
         if constexpr (OUT != 0) {
             __syncthreads();
             // (a fresh opaque copy of the lane index: everything the phase derives from it -- addresses, the re-read of the rows -- is computed
@@ -797,8 +838,14 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             }
         }
         __syncthreads();
+        L8_STAMP(3)
         par ^= 1;
     }
+#ifdef LLK8_TIMING
+    if (wave == 1 && lane_entry == 0) sm[cfg::OFF_FLAG + 1] = (double)tq[2];
+    __syncthreads();
+#endif
+    if (pf_acc == 0x7FF12345 && p.llks) p.llks[0] = 0.0;  // (never: the upper dword pattern of no finite double this code produces; keeps the touches alive)
     if (wave == 0 && scal) {
         const double v2 = wave_sum(run_llk), v3 = wave_sum(run_w);
         if (lane_entry == 0) {
@@ -811,6 +858,14 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             sc[5] = 0.0;
             sc[6] = 0.0;
             sc[7] = 0.0;
+#ifdef LLK8_TIMING
+            sc[SC_SQERR] = (double)tq[0];      // contractions (wave 0)
+            sc[SC_DEVSQ] = (double)tq[1];      // second staging (wave 0)
+            sc[SC_NONEMPTY] = (double)tq[2];   // hand-off + solver + table request (wave 0)
+            sc[5] = (double)tq[3];             // wait at the round's last barrier (wave 0)
+            sc[6] = (double)tq[4];             // waits at the other barriers (wave 0)
+            sc[7] = sm[cfg::OFF_FLAG + 1];     // overlapped staging of the next first tile (wave 1)
+#endif
         }
     }
 }
