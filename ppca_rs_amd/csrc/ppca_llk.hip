@@ -449,10 +449,21 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             const_cast<double *>(Xwg + (int64_t)rel0 * p.ldx), 0, cnt * rowbytes, 0x00020000);
         pf_acc |= (int)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, lane_entry * 128, wave * RPW * rowbytes, 0);
     };
-    // wave unit of the Gram: packed-column tile ct, row tile rt; of b: row tile rtb, quarter kq of the dimensions
+    // Contraction units.  LLK8_ROLES = 0 (rounds 4-5): every wave one Gram unit (packed-column tile ct, row tile rt) + one b unit (row
+    // tile rtb, quarter kq of the dimensions).  LLK8_ROLES = 1 (round 6): waves 0-3 the Gram of column tile ct = wave for BOTH row tiles
+    // (one table slice, two units), waves 4-7 b of row tile rtb for one HALF of the dimensions (two of the old units in one loop: two
+    // K-split partials instead of four).  The same MFMAs per SIMD (wave w and w + 4 share one); what it buys: the solver step runs on a
+    // b wave (wave 4), which holds no table slice -- the solver wave of rounds 4-5 dropped its slice for the solver step and requested
+    // the 32 KB again behind it, ~2 k cycles of request issue on the round's critical path (phase table of the LLK8_TIMING build).
+#ifndef LLK8_ROLES
+#define LLK8_ROLES 1
+#endif
+    constexpr bool ROLES = LLK8_ROLES != 0;
+    constexpr int SOLVER = ROLES ? 4 : 0;
     const int ct = wave & 3, rt = wave >> 2;
     const int rtb = wave & 1, kq = wave >> 1;
-    const bool gram_wave = ct < NTP;
+    const bool is_gram = !ROLES || wave < 4, is_b = !ROLES || wave >= 4;
+    const bool gram_wave = is_gram && ct < NTP;
     // the unit's slice of the digit table, resident (128 registers).  The solver wave cannot hold it next to the packed
     // factor (110 registers): it drops the slice for its solver step and requests it again right after (32 loads from
     // L2 that travel under the next staging) -- a spill through scratch would wait on the row loads in flight instead.
@@ -469,7 +480,16 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                 qt[sl][kc] = i4_t{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
             }
     };
-    load_table();
+    // The slice's registers declared dead (no instruction): hipcc's liveness is not path-sensitive -- it does not know that the wave in
+    // the solver branch (wave 4) is never a Gram wave, and kept the 128 registers alive across the solver's 110 (hundreds of spills).
+    auto kill_table = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < QS; ++sl)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) asm volatile("" : "=v"(qt[sl][kc]));
+    };
+    if (is_gram) load_table();
+    else kill_table();
     const double qs = gram_wave ? p.qscale[16 * ct + (lane_entry & 15)] : 0.0;
 
     auto stage_tile = [&](int lane, int slot, int par) {
@@ -516,19 +536,21 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
         // (profiles/r04/mfma_peak.txt), and K = 10 columns are three groups of 4 instead of one padded tile of 16; the A operand
         // is the one the 16x16x4 form read, the B operand three LDS reads per k-step (the same address in the four blocks).
         constexpr int NCB = (K + 3) / 4;
-        double accb[NCB];
-        int ccol[NCB];
+        if (is_b) {
+            // the unit: row tile rb, dimensions [dim0, dim0 + 4 NST); its partial of b goes to the row's b slots (part 0) or to B1
+            const int rb = rtb;
+            const int part = ROLES ? (wave - 4) >> 1 : kq;
+            constexpr int NST = ROLES ? 2 * STEPS : STEPS;
+            const int dim0 = (ROLES ? 2 * DPQ : DPQ) * part;
+            double accb[NCB];
+            int ccol[NCB];
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            accb[c] = 0.0;
-            ccol[c] = 4 * c + (lane & 3) < K ? 4 * c + (lane & 3) : K;  // (column K of the tile of C is zero)
-        }
-        const double *xrow = Xs + (16 * rtb + l15) * XS + DPQ * kq + l4;
-        const double *cpc = Cs + (DPQ * kq + l4) * CS;
-        unsigned long long mwd[4];
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) mwd[kc] = Ms[(mr + 16 * rt + l15) * 4 + kc];
-        {
+            for (int c = 0; c < NCB; ++c) {
+                accb[c] = 0.0;
+                ccol[c] = 4 * c + (lane & 3) < K ? 4 * c + (lane & 3) : K;  // (column K of the tile of C is zero)
+            }
+            const double *xrow = Xs + (16 * rb + l15) * XS + dim0 + l4;
+            const double *cpc = Cs + (dim0 + l4) * CS;
             constexpr int CH = 2;
             double axb[2][CH], cbb[2][CH][NCB];
 #pragma unroll
@@ -538,8 +560,8 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                 for (int cc = 0; cc < NCB; ++cc) cbb[0][u][cc] = cpc[4 * u * CS + ccol[cc]];
             }
 #pragma unroll
-            for (int c = 0; c < STEPS / CH; ++c) {
-                if (c + 1 < STEPS / CH) {
+            for (int c = 0; c < NST / CH; ++c) {
+                if (c + 1 < NST / CH) {
 #pragma unroll
                     for (int u = 0; u < CH; ++u) {
                         axb[(c + 1) & 1][u] = xrow[4 * ((c + 1) * CH + u)];
@@ -555,43 +577,51 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                         accb[cc] = __builtin_amdgcn_mfma_f64_4x4x4f64(axb[c & 1][u], cbb[c & 1][u][cc], accb[cc], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        i4_t af[4];
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const unsigned bits = (unsigned)(mwd[kc] >> (16 * l4)) & 0xFFFFu;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) af[kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
-        }
-        double v[4];
-#pragma unroll
-        for (int g = 0; g < QS / 2; ++g) {
-            const int sl = QS - 2 - 2 * g;
-            i4_t ia[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                ia[u] = i4_t{0, 0, 0, 0};
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[kc], qt[sl + u][kc], ia[u], 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int part = ia[1][r] * QBASE + ia[0][r];
-                v[r] = g == 0 ? (double)part : v[r] * (double)(QBASE * QBASE) + (double)part;
-            }
-        }
-        if (gram_wave) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Gs[(slot * B + 16 * rt + 4 * l4 + r) * GS + 16 * ct + l15] = v[r] * qs;
-        }
-        {   // the four K-split partials of b, summed by the solver in a fixed order
-            const int row = slot * B + 16 * rtb + 4 * ((lane >> 2) & 3) + l4;  // D[i][j] of block b: lane 16 i + 4 b + j
+            // the K-split partials of b, summed by the solver in a fixed order
+            const int row = slot * B + 16 * rb + 4 * ((lane >> 2) & 3) + l4;  // D[i][j] of block b: lane 16 i + 4 b + j
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
                 const int col = 4 * c + (lane & 3);
-                if (kq == 0) Gs[row * GS + 16 * NTP + col] = accb[c];
-                else B1[((kq - 1) * 2 * B + row) * BS + col] = accb[c];
+                if (part == 0) Gs[row * GS + 16 * NTP + col] = accb[c];
+                else B1[((part - 1) * 2 * B + row) * BS + col] = accb[c];
             }
+        }
+        if (is_gram) {
+            // Gram units of this wave: column tile ct, row tile rg
+            static_for<ROLES ? 2 : 1>([&](auto u_tag) {
+                const int rg = ROLES ? decltype(u_tag)::value : rt;
+                unsigned long long mwd[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) mwd[kc] = Ms[(mr + 16 * rg + l15) * 4 + kc];
+                i4_t af[4];
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const unsigned bits = (unsigned)(mwd[kc] >> (16 * l4)) & 0xFFFFu;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) af[kc][u] = (int)((((bits >> (4 * u)) & 0xFu) * 0x00204081u) & 0x01010101u);
+                }
+                double v[4];
+#pragma unroll
+                for (int g = 0; g < QS / 2; ++g) {
+                    const int sl = QS - 2 - 2 * g;
+                    i4_t ia[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        ia[u] = i4_t{0, 0, 0, 0};
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) ia[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[kc], qt[sl + u][kc], ia[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int part = ia[1][r] * QBASE + ia[0][r];
+                        v[r] = g == 0 ? (double)part : v[r] * (double)(QBASE * QBASE) + (double)part;
+                    }
+                }
+                if (gram_wave) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Gs[(slot * B + 16 * rg + 4 * l4 + r) * GS + 16 * ct + l15] = v[r] * qs;
+                }
+            });
         }
     };
 
@@ -665,13 +695,13 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
         __syncthreads();
         L8_STAMP(4)
         const bool more = tile + 2 < tile_end;  // (wave-uniform)
-        if (wave == 0) {
-            if (more) {  // this wave's four rows of the next round's first tile: RAW into the (free) x~ tile, one for each of waves 1..4
+        if (wave == SOLVER) {
+            if (more) {  // this wave's four rows of the next round's first tile: RAW into the (free) x~ tile, one for each of four other waves
                 typedef double d2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
-                    *reinterpret_cast<d2_t *>(Xs + r * XS + 2 * lane) = d2_t{xr[r][0], xr[r][1]};
-                    *reinterpret_cast<d2_t *>(Xs + r * XS + 128 + 2 * lane) = d2_t{xr[r][2], xr[r][3]};
+                    *reinterpret_cast<d2_t *>(Xs + (SOLVER * RPW + r) * XS + 2 * lane) = d2_t{xr[r][0], xr[r][1]};
+                    *reinterpret_cast<d2_t *>(Xs + (SOLVER * RPW + r) * XS + 128 + 2 * lane) = d2_t{xr[r][2], xr[r][3]};
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(hand, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -698,33 +728,33 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             int pe;
             post.factor([&](int e) { return g0[e]; }, s2, pm, pe);
             if constexpr (OUT == 0) {
-                const double quad = post.forward_quad([&](int a) { return ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; });
+                const double quad = post.forward_quad([&](int a) { return ROLES ? g0[16 * NTP + a] + b1[a] : ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; });
                 const double lk = sample_llk(xx, quad, lean_log(pm) + (double)pe * LN_2, s2, lnsig, m, K);
                 run_llk += wgt * lk;
                 run_w += wgt;
                 if (p.llks && mine) p.llks[row] = lk;
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef LLK8_EXP_NORELOAD  // (timing experiment, results wrong: the solver wave keeps a stale table slice)
-                load_table();
-#endif
+                if constexpr (!ROLES) load_table();
+                else kill_table();  // (LLK8_ROLES = 1: the solver wave is a b wave and holds no slice)
             } else {
                 double z[K], quad, zz;
-                post.solve([&](int a) { return ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; }, z, quad, zz);
+                post.solve([&](int a) { return ROLES ? g0[16 * NTP + a] + b1[a] : ((g0[16 * NTP + a] + b1[a]) + b1[2 * B * BS + a]) + b1[4 * B * BS + a]; }, z, quad, zz);
                 double *zr = B1 + lane * BS;  // (the first b partial of the sample is dead: its z goes there)
 #pragma unroll
                 for (int a = 0; a < K; ++a) zr[a] = z[a];
                 (void)xx; (void)m; (void)wgt; (void)pm; (void)pe;
+                if constexpr (ROLES) kill_table();
             }
           }
         }
 #ifndef LLK8_EXP_NOSTAGE0  // (timing experiment, results wrong: the rounds without the staging of their first tile)
         if (more) {  // the first tile of the next round (its rows have been in registers since this round's second staging)
             ++handed;
-            if (wave != 0) {
+            if (wave != SOLVER) {
                 stage_tile(lane, 0, par ^ 1);
                 load_tile(tile + 3);
 #ifndef LLK8_HAND_WAVES
-#define LLK8_HAND_WAVES 0x4321  // nibble r: the wave that stages row r of the solver wave
+#define LLK8_HAND_WAVES (LLK8_ROLES ? 0x1765 : 0x4321)  // nibble r: the wave that stages row r of the solver wave (its SIMD's other wave is spared)
 #endif
                 const int hrow = wave == ((LLK8_HAND_WAVES >> 0) & 15) ? 0 : wave == ((LLK8_HAND_WAVES >> 4) & 15) ? 1
                                : wave == ((LLK8_HAND_WAVES >> 8) & 15) ? 2 : wave == ((LLK8_HAND_WAVES >> 12) & 15) ? 3 : -1;
@@ -735,7 +765,7 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                         __builtin_amdgcn_s_sleep(1);
                     }
                     asm volatile("" ::: "memory");
-                    stage_one(lane, hrow, hrow, par ? 0 : 2 * B);
+                    stage_one(lane, SOLVER * RPW + hrow, hrow, par ? 0 : 2 * B);
                 }
             }
         }
@@ -751,8 +781,9 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
             typedef unsigned u4_t __attribute__((ext_vector_type(4)));
             constexpr int NR = 2 * RPW;  // rows of the round per wave
             // Order of the phase: [extrapolate: the re-read of the wave's rows] -> the 2 x NR output pieces into registers -> the
-            // request of the wave's table slice -> the stores.  Loads and stores share one in-order counter: the slice requested
-            // BEHIND the stores would come back only after the stores are acknowledged (the next contraction waited for that).
+            // stores -> the Gram waves' request of their table slices (requested in front of the stores -- so that the slices do
+            // not wait for the stores' acknowledgement on the one in-order counter -- measured the same and, with the contraction
+            // split by roles, no longer fits the registers).
             u4_t ov[NR][2];
             if constexpr (OUT == 2) {
 #pragma unroll
@@ -781,10 +812,15 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                     }
                     mu2[h] = *reinterpret_cast<const d2_t *>(sm + cfg::OFF_MU + 128 * h + 2 * lo);
                 }
+                int chain = 0;
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const int si = NR * wave + r;  // sample of the round: slot si >> 5, row si & 31 of its tile
-                    const double *zr = B1 + si * BS;
+                    // (the row's z address goes through an opaque statement that also takes the previous row's result: hipcc otherwise
+                    //  requests the z of all eight rows at once -- 160 registers -- and spills the table slice it is about to reload)
+                    int zo = si * BS;
+                    asm volatile("" : "+v"(zo) : "v"(chain));
+                    const double *zr = B1 + zo;
                     double o[2][2];
 #pragma unroll
                     for (int h = H0; h < H1; ++h) {
@@ -812,6 +848,7 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                         }
                         const long long b0 = __double_as_longlong(o[h][0]), b1v = __double_as_longlong(o[h][1]);
                         ov[r][h] = u4_t{(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1v, (unsigned)(b1v >> 32)};
+                        chain = (int)b0;
                     }
                 }
             };
@@ -822,8 +859,6 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                 __builtin_amdgcn_sched_barrier(0);
                 form(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
             }
-            __builtin_amdgcn_sched_barrier(0);
-            load_table();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -836,6 +871,9 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
                 __builtin_amdgcn_raw_buffer_store_b128(ov[r][0], orow, lo * 16, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(ov[r][1], orow, lo * 16, 1024, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (is_gram) load_table();
+            else kill_table();
         }
         __syncthreads();
         L8_STAMP(3)
@@ -846,7 +884,7 @@ __device__ __forceinline__ void llk8_run(const PassArgs &p, double *sm, const in
     __syncthreads();
 #endif
     if (pf_acc == 0x7FF12345 && p.llks) p.llks[0] = 0.0;  // (never: the upper dword pattern of no finite double this code produces; keeps the touches alive)
-    if (wave == 0 && scal) {
+    if (wave == SOLVER && scal) {
         const double v2 = wave_sum(run_llk), v3 = wave_sum(run_w);
         if (lane_entry == 0) {
             double *sc = scal;
