@@ -589,8 +589,13 @@ __global__ __launch_bounds__(256) void gen_colstat_kernel(const double *V, int64
     part[((int64_t)blockIdx.y * 2 + 1) * kp + c] = sm;
 }
 // -> scale[c] and the chunk's guard flag (flags[1], reset by gen_colstat_kernel); sums in block order (deterministic)
+// (round 6) pred / redo_col: the chunk's digits were already cut by gen_wdigits_pred_kernel under pred[c] (use_pred = 1).  The column
+// keeps that scale if it is the power of two the cut derived from it and lies within [1, 4] x the scale of the column's own maximum
+// (no overflow of the 8 x 7-bit form, at most two bits coarser); otherwise the column is marked in redo_col (and flags[2] raised) and
+// gen_wdigits_kernel cuts it again under its own scale.  scale[c] = the scale the digits in BtW carry either way; pred[c] for the
+// NEXT chunk = twice the scale of this chunk's maximum (one bit of room upwards).
 __global__ __launch_bounds__(256) void gen_colscale_kernel(const double *part, int nblocks, int64_t n, int kp, double *scale,
-                                                           int *flags) {
+                                                           int *flags, double *pred, int *redo_col, int use_pred) {
     // one workgroup per column: thread t takes blocks t, t + 256, ..., then a fixed tree over the threads
     // (deterministic; one THREAD per column walked a million-row chunk's 4096 block partials alone: 1 ms per chunk)
     __shared__ double rmx[256], rsm[256], rmn[256];
@@ -624,43 +629,167 @@ __global__ __launch_bounds__(256) void gen_colscale_kernel(const double *part, i
         mn = rmn[0];
         int e = 0;
         if (mx > 0.0 && mx < 1.0e300) (void)frexp(mx, &e);
-        scale[c] = ldexp(1.0, e - (7 * GQS - 2));
+        const double own = ldexp(1.0, e - (7 * GQS - 2));
+        double used = own;
+        int redo = use_pred;
+        if (use_pred) {
+            const double ps = pred[c];
+            if (ps > 0.0 && ps < 1.0e300) {
+                int pe = 0;
+                (void)frexp(ps, &pe);
+                const double pc = ldexp(1.0, pe - 1);  // (what gen_wdigits_pred_kernel made of it)
+                if (pc == ps && own <= pc && pc <= 4.0 * own) {
+                    used = pc;
+                    redo = 0;
+                }
+            }
+        }
+        scale[c] = used;
+        if (redo_col) {
+            redo_col[c] = redo;
+            if (redo) {
+                atomicOr(&flags[2], 1);
+                atomicAdd(&flags[3], 1);  // (diagnostic count, PPCA_GEN_WPRED_STATS)
+            }
+        }
+        if (pred) pred[c] = 2.0 * own;
         // finite, and the maximum within 2^20 of the mean magnitude of EVERY 256-row block (round 4: the mean over the whole
         // chunk is dominated by the very row that breaks the form -- one row at 1e6 x the others passed "max <= 2^20 x mean"
-        // whenever the chunk had fewer than 2^20 rows, and the dimensions masked in that row summed rows cut at 14 bits)
-        if (!(sm < 1.0e300) || !(mx <= 1048576.0 * mn)) atomicOr(&flags[1], 1);
+        // whenever the chunk had fewer than 2^20 rows, and the dimensions masked in that row summed rows cut at 14 bits);
+        // under a predicted (coarser) scale the bound tightens by the same factor: the same absolute precision is guaranteed
+        if (!(sm < 1.0e300) || !(mx * (used / own) <= 1048576.0 * mn)) atomicOr(&flags[1], 1);
     }
 }
 
 // digits of V[n][kp] (row-major) -> planes BtW[s][c][npad] (samples contiguous): 64 samples x 64 columns per
 // workgroup, lane = column (rows read as whole 512-byte segments), wave w = samples 16 w .. 16 w + 15 -- the 16 digits
 // of one (slice, column) are 16 consecutive bytes of the output: one 16-byte store, no transposition
-__global__ __launch_bounds__(256) void gen_wdigits_kernel(const double *V, int64_t n, int kp, int64_t npad, const double *scale,
-                                                          signed char *BtW, const int *flags) {
+// redo_col != nullptr: only the columns marked there (flags[2] = any), see gen_colscale_kernel.  Grid (ceil(kp / 64), any): a workgroup
+// walks the 64-row tiles blockIdx.y, blockIdx.y + gridDim.y, ...
+__global__ __launch_bounds__(256) void gen_wdigits_kernel(const double *V, int64_t n, int64_t ncpad, int kp, int64_t npad,
+                                                          const double *scale, signed char *BtW, const int *flags, const int *redo_col) {
     if (flags[1]) return;
+    if (redo_col && !flags[2]) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t i0 = (int64_t)blockIdx.y * 64 + 16 * wave;
     const int c = blockIdx.x * 64 + lane;
-    double v[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = (i0 + e < n && c < kp) ? V[(i0 + e) * kp + c] : 0.0;
-    if (c >= kp) return;
-    int ex;
-    (void)frexp(scale[c], &ex);  // scale = 2^(ex - 1)
+    const bool mine = c < kp && (!redo_col || redo_col[c] != 0);
+    if (__ballot(mine) == 0ull) return;
+    int ex = 0;
+    if (mine) (void)frexp(scale[c], &ex);  // scale = 2^(ex - 1)
     const int shift = -(ex - 1);
-    union { signed char b[GQS][16]; gi4_t q[GQS]; } u;
+    for (int64_t i0 = (int64_t)blockIdx.y * 64 + 16 * wave; i0 < ncpad; i0 += (int64_t)gridDim.y * 64) {
+        double v[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        long long I = llrint(ldexp(v[e], shift));
+        for (int e = 0; e < 16; ++e) v[e] = (i0 + e < n && mine) ? V[(i0 + e) * kp + c] : 0.0;
+        if (!mine) continue;
+        union { signed char b[GQS][16]; gi4_t q[GQS]; } u;
 #pragma unroll
-        for (int sl = 0; sl < GQS; ++sl) {
-            const int dig = (int)((I + 64) & 127) - 64;
-            I = (I - dig) >> 7;
-            u.b[sl][e] = (signed char)dig;
+        for (int e = 0; e < 16; ++e) {
+            long long I = llrint(ldexp(v[e], shift));
+#pragma unroll
+            for (int sl = 0; sl < GQS; ++sl) {
+                const int dig = (int)((I + 64) & 127) - 64;
+                I = (I - dig) >> 7;
+                u.b[sl][e] = (signed char)dig;
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < GQS; ++sl) *reinterpret_cast<gi4_t *>(BtW + ((int64_t)sl * kp + c) * npad + i0) = u.q[sl];
+    }
+}
+
+// (round 6) The digit planes of a chunk's wP in full 128-byte lines, and -- STATS -- gen_colstat_kernel's column statistics from the
+// same registers.
+//   Lane layout: a wave = 8 row groups x 8 columns (lane = 8 rg + cc): lane (rg, cc) holds rows 16 rg .. 16 rg + 15 of a 128-row tile
+//   for column c0 + cc, so the 16-byte stores of the eight lanes of a column make one whole line of BtW[slice][column][sample].
+//   gen_wdigits_kernel's layout (lane = column, 16 rows per wave) writes 16 bytes of each of 64 lines per store instruction: by
+//   ablation (profiles/r06/wdigits_ablation.log) 770 of its 830 us per chunk at config 4 were those stores, the loads + statistics 260,
+//   the digit arithmetic 150.  The loads pay for it with 64-byte pieces (the four waves of the workgroup cover 256 contiguous bytes).
+//   STATS: the digits are cut under the scales PREDICTED from the previous chunk of the same call (scale_in = pred[c], a power of two;
+//   anything else: the column is not cut) while maxima / sums of |v| over the 256-row block go to part[block][2][kp] as
+//   gen_colstat_kernel writes them (the sum in a fixed tree: per lane over its rows in order, the two tiles, then the row groups);
+//   gen_colscale_kernel then accepts or rejects the prediction per column.  Saves the second read of wP (16.6 KB per sample at k = 64).
+//   !STATS: the first chunk of a call -- its scales are known (scale_in = scale[c]), the chunk's guard (flags[1]) is honoured.
+// Workgroup = 256 rows (two tiles) x 32 columns; grid (ceil(kp / 32), ceil(n / 256)).
+// (stats is a run-time argument, the statistics are always computed: as a template parameter the instantiation without them came out
+//  at 1 260 us per chunk against 570 with them -- its loads sank into the branch that cuts the digits)
+__global__ __launch_bounds__(256) void gen_wdigits_lines_kernel(const double *V, int64_t n, int64_t ncpad, int kp, int64_t npad,
+                                                                const double *scale_in, signed char *BtW, double *part, int *flags,
+                                                                int stats) {
+    if (stats) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            flags[1] = 0;
+            flags[2] = 0;
+        }
+    } else {
+        if (flags[1]) return;
+    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int rg = lane >> 3, cc = lane & 7;
+    const int c = blockIdx.x * 32 + 8 * wave + cc;
+    const bool okc = c < kp;
+    int shift = 0;
+    bool cut = false;
+    if (okc) {
+        const double ps = scale_in[c];
+        if (ps > 0.0 && ps < 1.0e300) {
+            int ex;
+            (void)frexp(ps, &ex);  // scale = 2^(ex - 1)
+            shift = -(ex - 1);
+            cut = true;
         }
     }
+    double mx = 0.0, sm = 0.0;
+    const int64_t ib = (int64_t)blockIdx.y * 256 + 16 * rg;
+    double v[16];
 #pragma unroll
-    for (int sl = 0; sl < GQS; ++sl) *reinterpret_cast<gi4_t *>(BtW + ((int64_t)sl * kp + c) * npad + i0) = u.q[sl];
+    for (int e = 0; e < 16; ++e) v[e] = (ib + e < n && okc) ? V[(ib + e) * kp + c] : 0.0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int64_t i0 = ib + 128 * it;
+        double vn[16];
+        if (it == 0) {  // (the second tile's rows are requested before the first tile's digits are cut)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vn[e] = (i0 + 128 + e < n && okc) ? V[(i0 + 128 + e) * kp + c] : 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const double a = fabs(v[e]);
+            mx = fmax(mx, a);  // (a NaN leaves the maximum alone; the sum carries it into the guard)
+            sm += a;
+        }
+        if (cut && i0 < ncpad) {
+            union { signed char b[GQS][16]; gi4_t q[GQS]; } u;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                long long I = llrint(ldexp(v[e], shift));
+#pragma unroll
+                for (int sl = 0; sl < GQS; ++sl) {
+                    const int dig = (int)((I + 64) & 127) - 64;
+                    I = (I - dig) >> 7;
+                    u.b[sl][e] = (signed char)dig;
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < GQS; ++sl) *reinterpret_cast<gi4_t *>(BtW + ((int64_t)sl * kp + c) * npad + i0) = u.q[sl];
+        }
+        if (it == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = vn[e];
+        }
+    }
+    {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            mx = fmax(mx, __shfl_xor(mx, o));
+            sm += __shfl_xor(sm, o);
+        }
+        if (stats && rg == 0 && okc) {
+            part[((int64_t)blockIdx.y * 2) * kp + c] = mx;
+            part[((int64_t)blockIdx.y * 2 + 1) * kp + c] = sm;
+        }
+    }
 }
 
 // C[M x N] (+)= scale[c] * sum_s 128^s ( A[M x K] . Bt[s][N x K]^T ), bytes, K a multiple of 64.
@@ -2477,8 +2606,8 @@ struct GenWs {
     // int8-sliced contractions
     unsigned char *A, *AT;
     signed char *BtQ, *BtW;
-    double *scaleQ, *scaleW, *colpart, *rmin, *spart;
-    int *flags;
+    double *scaleQ, *scaleW, *predW, *colpart, *rmin, *spart;
+    int *flags, *redoW;
     int dpad;
     int64_t npad;
     // two-kernel EM pass for 11 <= k <= 16, d <= 256 (ppca_em16.hip): rows handed between the kernels, tile masks,
@@ -2513,6 +2642,8 @@ static size_t carve_impl(void *ws, int d, int k, int64_t n, GenWs *out) {
     w.BtW = static_cast<signed char *>(take((size_t)GQS * kp * w.npad));
     w.scaleQ = static_cast<double *>(take(sizeof(double) * (size_t)kp));
     w.scaleW = static_cast<double *>(take(sizeof(double) * (size_t)kp));
+    w.predW = static_cast<double *>(take(sizeof(double) * (size_t)kp));
+    w.redoW = static_cast<int *>(take(sizeof(int) * (size_t)kp));
     w.colpart = static_cast<double *>(take(sizeof(double) * 2 * (size_t)kp * (size_t)((w.chunk + 255) / 256)));
     w.rmin = static_cast<double *>(take(256));
     w.spart = static_cast<double *>(take(sizeof(double) * 5 * (size_t)((w.chunk + SCAL_ROWS - 1) / SCAL_ROWS)));
@@ -2890,13 +3021,35 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         if (em) {
             if (i8) {
                 // column scales of wP over the chunk + its guard (flags[1]), digit planes, S += Mask^T . wP on the int8 MFMA
+                // (round 6) from the call's second chunk on the digits are cut in the same pass that takes the column statistics, under
+                // the scales predicted from the chunk before (gen_wdigits_pred_kernel); the first chunk of a call takes the statistics
+                // first -- so that a result never depends on an earlier call.  PPCA_GEN_WPRED=0: every chunk as the first.
+                static const bool wpred = [] {
+                    const char *e = getenv("PPCA_GEN_WPRED");
+                    return !(e && atoi(e) == 0);
+                }();
                 const int nb = (int)((nc + 255) / 256);
-                hipLaunchKernelGGL(gen_colstat_kernel, dim3((unsigned)((kp + 255) / 256), (unsigned)nb), dim3(256), 0, s, W.G,
-                                   nc, (int)kp, W.colpart, W.flags);
-                hipLaunchKernelGGL(gen_colscale_kernel, dim3((unsigned)kp), dim3(256), 0, s, W.colpart, nb, nc, (int)kp, W.scaleW,
-                                   W.flags);
                 dim3 dg((unsigned)((kp + 63) / 64), (unsigned)(ncpad / 64));
-                hipLaunchKernelGGL(gen_wdigits_kernel, dg, dim3(256), 0, s, W.G, nc, (int)kp, W.npad, W.scaleW, W.BtW, W.flags);
+                const dim3 lg((unsigned)((kp + 31) / 32), (unsigned)nb);
+                if (wpred && r0 > 0) {
+                    hipLaunchKernelGGL(gen_wdigits_lines_kernel, lg, dim3(256), 0, s, W.G, nc, ncpad, (int)kp, W.npad, W.predW,
+                                       W.BtW, W.colpart, W.flags, 1);
+                    hipLaunchKernelGGL(gen_colscale_kernel, dim3((unsigned)kp), dim3(256), 0, s, W.colpart, nb, nc, (int)kp, W.scaleW,
+                                       W.flags, W.predW, W.redoW, 1);
+                    hipLaunchKernelGGL(gen_wdigits_kernel, dim3(dg.x, std::min<unsigned>(dg.y, 32u)), dim3(256), 0, s, W.G, nc, ncpad, (int)kp,
+                                       W.npad, W.scaleW, W.BtW, W.flags, W.redoW);
+                } else {
+                    hipLaunchKernelGGL(gen_colstat_kernel, dim3((unsigned)((kp + 255) / 256), (unsigned)nb), dim3(256), 0, s, W.G,
+                                       nc, (int)kp, W.colpart, W.flags);
+                    hipLaunchKernelGGL(gen_colscale_kernel, dim3((unsigned)kp), dim3(256), 0, s, W.colpart, nb, nc, (int)kp, W.scaleW,
+                                       W.flags, W.predW, (int *)nullptr, 0);
+                    if (wpred)
+                        hipLaunchKernelGGL(gen_wdigits_lines_kernel, lg, dim3(256), 0, s, W.G, nc, ncpad, (int)kp, W.npad,
+                                           W.scaleW, W.BtW, W.colpart, W.flags, 0);
+                    else
+                        hipLaunchKernelGGL(gen_wdigits_kernel, dg, dim3(256), 0, s, W.G, nc, ncpad, (int)kp, W.npad, W.scaleW, W.BtW,
+                                           W.flags, (const int *)nullptr);
+                }
                 GTRY(hipGetLastError());
                 I8GemmArgs q{};
                 q.A = W.AT; q.lda = W.npad; q.Bt = W.BtW; q.ldb = W.npad; q.plane = kp * W.npad;
@@ -2986,6 +3139,20 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
                 else hipLaunchKernelGGL((recon2_kernel<64>), rg, dim3(256), 0, s, Xc, ldx, nc, d, k, model, W.Bz, W.G, recon_mode, recon + r0 * d, rpb);
             }
             GTRY(hipGetLastError());
+        }
+    }
+    if (em && i8) {
+        static const bool wstats = [] {
+            const char *e = getenv("PPCA_GEN_WPRED_STATS");
+            return e && atoi(e) == 1;
+        }();
+        if (wstats) {  // (diagnostic: columns cut a second time since the last report)
+            int f = 0;
+            GTRY(hipMemcpyAsync(&f, W.flags + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+            GTRY(hipMemsetAsync(W.flags + 3, 0, sizeof(int), s));
+            GTRY(hipStreamSynchronize(s));
+            fprintf(stderr, "[generic wP digits] %d of %lld (column, chunk) pairs cut a second time (chunks of %lld rows)\n", f,
+                    (long long)(kp * std::max<int64_t>(0, (n + W.chunk - 1) / W.chunk - 1)), (long long)W.chunk);
         }
     }
     return hipSuccess;
