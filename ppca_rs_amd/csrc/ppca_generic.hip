@@ -760,19 +760,32 @@ __global__ __launch_bounds__(256) void gen_wdigits_lines_kernel(const double *V,
             sm += a;
         }
         if (cut && i0 < ncpad) {
-            union { signed char b[GQS][16]; gi4_t q[GQS]; } u;
+            // I = rint(v 2^shift) as hi 2^28 + lo in 32-bit halves (the 64-bit form -- llrint, eight 64-bit add / shift pairs -- was 150 of
+            // the kernel's 570 us): hi = rint(y 2^-28), lo = rint(y - hi 2^28) -- the difference is exact (a multiple of ulp(y) below
+            // 2^27) and hi 2^28 is even, so hi 2^28 + lo = rint(y) including the ties.  Four balanced 7-bit digits from lo, its carry
+            // into hi, four from hi (the last one takes what is left, as before).
+            static_assert(GQS == 8, "two 28-bit halves");
+            gi4_t q[GQS];
+#pragma unroll
+            for (int sl = 0; sl < GQS; ++sl) q[sl] = gi4_t{0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                long long I = llrint(ldexp(v[e], shift));
+                const double y = ldexp(v[e], shift);
+                const double hf = __builtin_rint(ldexp(y, -28));
+                const double lf = __builtin_rint(y - ldexp(hf, 28));
+                int lo = (int)lf, hi = (int)hf;
 #pragma unroll
                 for (int sl = 0; sl < GQS; ++sl) {
-                    const int dig = (int)((I + 64) & 127) - 64;
-                    I = (I - dig) >> 7;
-                    u.b[sl][e] = (signed char)dig;
+                    if (sl == 4) hi += lo;  // (what the four low digits left: -1, 0 or 1)
+                    int &I = sl < 4 ? lo : hi;
+                    const int t7 = I + 64;
+                    const int dig = (t7 & 127) - 64;
+                    I = t7 >> 7;
+                    q[sl][e >> 2] |= (dig & 255) << (8 * (e & 3));
                 }
             }
 #pragma unroll
-            for (int sl = 0; sl < GQS; ++sl) *reinterpret_cast<gi4_t *>(BtW + ((int64_t)sl * kp + c) * npad + i0) = u.q[sl];
+            for (int sl = 0; sl < GQS; ++sl) *reinterpret_cast<gi4_t *>(BtW + ((int64_t)sl * kp + c) * npad + i0) = q[sl];
         }
         if (it == 0) {
 #pragma unroll
@@ -3036,7 +3049,7 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
                                        W.BtW, W.colpart, W.flags, 1);
                     hipLaunchKernelGGL(gen_colscale_kernel, dim3((unsigned)kp), dim3(256), 0, s, W.colpart, nb, nc, (int)kp, W.scaleW,
                                        W.flags, W.predW, W.redoW, 1);
-                    hipLaunchKernelGGL(gen_wdigits_kernel, dim3(dg.x, std::min<unsigned>(dg.y, 32u)), dim3(256), 0, s, W.G, nc, ncpad, (int)kp,
+                    hipLaunchKernelGGL(gen_wdigits_kernel, dim3(dg.x, std::min<unsigned>(dg.y, 256u)), dim3(256), 0, s, W.G, nc, ncpad, (int)kp,
                                        W.npad, W.scaleW, W.BtW, W.flags, W.redoW);
                 } else {
                     hipLaunchKernelGGL(gen_colstat_kernel, dim3((unsigned)((kp + 255) / 256), (unsigned)nb), dim3(256), 0, s, W.G,

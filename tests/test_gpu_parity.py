@@ -1462,6 +1462,52 @@ def test_multi_component_step_equals_component_by_component(oracle, tmp_path):
     np.testing.assert_array_equal(multi["guard_engine"], np.array([0, 0, 1, 0]))
 
 
+def test_generic_wp_digits_under_predicted_scales(oracle, tmp_path):
+    """Round 6 (split pipeline, ppca_generic.hip): from a call's second chunk on, the int8 digit planes of wP are cut in the pass that
+    takes the column statistics, under scales predicted from the chunk before (gen_wdigits_lines_kernel; columns whose maximum left
+    the predicted window are cut a second time), and the planes are written as whole lines.  Against the three-kernel form of rounds
+    2-5 (PPCA_GEN_WPRED=0), a child process each (tools/wpred_check.py): one chunk -> bit-identical; several chunks -> 1e-11 of each
+    other and 1e-8 of the oracle (ppca_model.rs:294-325), including weights that jump by 2^20 between chunks, a chunk of zero
+    weights and a chunk whose guard trips."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"wpred_{flag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "wpred_check.py"), path],
+                           capture_output=True, text=True, env=dict(os.environ, PPCA_GEN_WPRED=flag), timeout=900)
+        assert r.returncode == 0 and "wpred check written" in r.stdout, (flag, r.stdout[-1500:], r.stderr[-2500:])
+        outs.append(np.load(path))
+    new, old = outs
+    np.testing.assert_array_equal(new["one_chunk"], old["one_chunk"])
+
+    def blocks(d, k):
+        kp = k * (k + 1) // 2
+        b = [0, d * k, d * k + d * kp, 2 * d * k + d * kp, 2 * d * k + d * kp + d, 2 * d * k + d * kp + 2 * d]
+        return list(zip(["cross", "S", "U", "sumx", "totals"], b[:-1], b[1:]))
+
+    def check(name, x, w, sigma, c, mean):
+        want = oracle.stats(x, float(sigma), c, mean, w)
+        for part, a, b in blocks(*c.shape):
+            assert _rel(new[name][a:b], old[name][a:b]) < 1e-11, (name, part)
+            assert _rel(new[name][a:b], want[a:b]) < 1e-8, (name, part)
+        assert _rel(new[name][b:], want[b:]) < 1e-8, name  # scalars
+
+    x, w = new["in_x"], new["in_w"]
+    m = (new["in_sigma"], new["in_c"], new["in_mean"])
+    check("one_chunk", x, w, *m)
+    check("chunks_256", x, w, *m)
+    check("weights_jump", x, new["in_w2"], *m)
+    check("zero_chunk", x, new["in_w3"], *m)
+    x4 = x.copy()
+    x4[700] = new["in_x4_row"]
+    check("outlier_chunk", x4, w, *m)
+    check("k64", new["k64_x"], None, new["k64_sigma"], new["k64_c"], new["k64_mean"])
+    check("d1100", new["d1100_x"], None, new["d1100_sigma"], new["d1100_c"], new["d1100_mean"])
+
+
 def test_multi_component_sweep_with_a_guard_tripping_component(P, oracle):
     """mix_llk8_kernel skips a component whose slice table tripped the dynamic-range guard; the fp64 instantiation behind the same
     flag serves it (mix.rs:137-149: llks of every component).  Against the oracle, with the tripping component in slot 2 of 4."""
