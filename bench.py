@@ -249,7 +249,7 @@ def sustained_mfma_from_profiles():
 SECONDARY = {
     # BASELINE.json configurations 2, 4 and 5 as SHORT legs of the default run, so that the driver's clock sees them too (round 5's
     # review: five rounds of config-4 / config-5 numbers were only ever on the builder's clock).  No CPU leg for them.
-    "cfg2": dict(n=1_000_000, d=256, k=10, mask=0.3, mask_kind=0, mask_run=0, warmup=3, steps=20, mixture=0),
+    "cfg2": dict(n=1_000_000, d=256, k=10, mask=0.3, mask_kind=0, mask_run=0, warmup=10, steps=50, mixture=0),
     "cfg4": dict(n=2_000_000, d=1024, k=64, mask=0.5, mask_kind=1, mask_run=512, warmup=1, steps=3, mixture=0),
     "cfg5": dict(n=5_000_000, d=256, k=10, mask=0.3, mask_kind=0, mask_run=0, warmup=9, steps=11, mixture=8),
 }
