@@ -401,15 +401,23 @@ __global__ __launch_bounds__(256) void gen_maskbytes_kernel(const double *X, int
 // One workgroup per 64 samples, looping over 64-dim blocks: every wave reads its 16 rows as whole 512-byte segments
 // (lane = dim); x~ and the block's rows of C go through LDS to the MFMA (A: this wave's own 16 rows; row stride 68
 // doubles: 8 banks per row, two passes per read, the minimum for 64 doubles).
+static size_t prep_lds(int nt) {  // xt [64][68] + cs [64][16 nt + 1] (+ 8 bytes to 16-byte alignment) + tile [64][80]
+    const size_t cs2 = 16 * (size_t)nt + 1;
+    return sizeof(double) * (64 * 68 + 64 * cs2 + ((64 * cs2) & 1)) + 64 * 80;
+}
 template <int NT>
 __global__ __launch_bounds__(256) void gen_prep_kernel(const double *X, int64_t ldx, int64_t n, int d, int dpad, int64_t npad,
                                                        const double *model, int k, unsigned char *A, unsigned char *AT,
                                                        double *xx, double *mcount, double *Bz, int want_bytes) {
-    constexpr int CT = NT < 2 ? NT : 2;  // column tiles of C in LDS at a time (static LDS stays under 64 KB)
+    // (round 6) all NT column tiles of the block's rows of C in LDS at once (k = 64: 33 KB; the whole image 73 KB of dynamic LDS, still
+    // two workgroups per CU): with two tiles at a time (static LDS under 64 KB, rounds 4-5) every 64-dimension block paid a second
+    // staging of C with a barrier on either side of it.
+    constexpr int CT = NT;
     constexpr int XS2 = 68, CS2 = 16 * CT + 1;
-    __shared__ __attribute__((aligned(16))) double xt[64 * XS2];
-    __shared__ __attribute__((aligned(16))) double cs[64 * CS2];
-    __shared__ __attribute__((aligned(16))) unsigned char tile[64][80];
+    extern __shared__ __attribute__((aligned(16))) double prep_sm[];
+    double *xt = prep_sm;                          // [64][XS2]
+    double *cs = xt + 64 * XS2;                    // [64][CS2]
+    unsigned char (*tile)[80] = reinterpret_cast<unsigned char (*)[80]>(cs + 64 * CS2 + (64 * CS2 & 1));  // [64][80], 16-byte aligned
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t i0 = (int64_t)blockIdx.x * 64;
@@ -2971,9 +2979,14 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
         const bool prep = prep_enabled() && k <= 64;
         if (prep) {  // row statistics, mask bytes and b = X~ C in one pass over the chunk's rows
             const dim3 pg((unsigned)(ncpad / 64));
-            if (k <= 16) hipLaunchKernelGGL((gen_prep_kernel<1>), pg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
-            else if (k <= 32) hipLaunchKernelGGL((gen_prep_kernel<2>), pg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
-            else hipLaunchKernelGGL((gen_prep_kernel<4>), pg, dim3(256), 0, s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
+            if (k <= 16) hipLaunchKernelGGL((gen_prep_kernel<1>), pg, dim3(256), prep_lds(1), s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
+            else if (k <= 32) hipLaunchKernelGGL((gen_prep_kernel<2>), pg, dim3(256), prep_lds(2), s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
+            else {
+                static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gen_prep_kernel<4>),
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds(4));
+                GTRY(attr);
+                hipLaunchKernelGGL((gen_prep_kernel<4>), pg, dim3(256), prep_lds(4), s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
+            }
             GTRY(hipGetLastError());
         } else {
             hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, s, Xc, ldx, nc, d, model, k,
