@@ -2982,9 +2982,15 @@ static hipError_t generic_run(const double *X, int64_t ldx, const double *w, int
             if (k <= 16) hipLaunchKernelGGL((gen_prep_kernel<1>), pg, dim3(256), prep_lds(1), s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
             else if (k <= 32) hipLaunchKernelGGL((gen_prep_kernel<2>), pg, dim3(256), prep_lds(2), s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
             else {
-                static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gen_prep_kernel<4>),
-                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds(4));
-                GTRY(attr);
+                static std::atomic<unsigned long long> prep_done{0ull};  // (per device, as the other kernels above 64 KB of LDS)
+                int dev = 0;
+                GTRY(hipGetDevice(&dev));
+                const unsigned long long bit = 1ull << (dev & 63);
+                if (!(prep_done.load(std::memory_order_acquire) & bit)) {
+                    GTRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&gen_prep_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)prep_lds(4)));
+                    prep_done.fetch_or(bit, std::memory_order_release);
+                }
                 hipLaunchKernelGGL((gen_prep_kernel<4>), pg, dim3(256), prep_lds(4), s, Xc, ldx, nc, d, W.dpad, W.npad, model, k, W.A, W.AT, W.xx, W.mc, W.Bz, i8 ? 1 : 0);
             }
             GTRY(hipGetLastError());
