@@ -1,5 +1,7 @@
 R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r6fz
+mkdir -p $OUT
 cd $R
-for r in 1 2; do timeout 120 python tools/time_passes.py 4000000 256 10 2>&1 | grep -E "llk|smooth|extrapolate" | head -3; done
-timeout 120 python tools/time_passes.py 4000000 200 10 2>&1 | grep -E "llk|smooth|extrapolate" | head -3
-timeout 900 python -m pytest tests -m gpu -x -q -k "output_rows or output_passes or extrapolate or smooth or eight_wave" 2>&1 | tail -3
+(for seed in 101 202 303; do PPCA_GEN_WPRED_STATS=1 timeout 900 python tools/fuzz_generic.py $seed 60 2>&1 | grep -v "of 0 (col" | tail -4; done) > $OUT/fuzz_generic.log 2>&1
+tail -3 $OUT/fuzz_generic.log
+timeout 600 python tools/soak_generic.py > $OUT/soak_generic.log 2>&1; tail -3 $OUT/soak_generic.log
