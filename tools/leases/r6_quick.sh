@@ -1,7 +1,11 @@
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r6fz
+OUT=$R/gpurun_out/r6dress
 mkdir -p $OUT
 cd $R
-(for seed in 101 202 303; do PPCA_GEN_WPRED_STATS=1 timeout 900 python tools/fuzz_generic.py $seed 60 2>&1 | grep -v "of 0 (col" | tail -4; done) > $OUT/fuzz_generic.log 2>&1
-tail -3 $OUT/fuzz_generic.log
-timeout 600 python tools/soak_generic.py > $OUT/soak_generic.log 2>&1; tail -3 $OUT/soak_generic.log
+SECONDS=0; python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err
+echo "wall ${SECONDS}s"
+python3 -c "
+import json
+j=json.loads(open('$OUT/bench_driver_cmd.json').read().strip().splitlines()[-1])
+print(j['value'], j['ms_per_step'], j['roofline']['frac'], j['cpu_baseline']['value'], {k:(round(v['value'],2), round(v['ms_per_step'],3)) for k,v in j['secondary'].items()})
+"
